@@ -1,0 +1,125 @@
+"""Split a model's decoder layers into contiguous pipeline stages.
+
+The reference hard-wires two workers with hand-edited half-open ranges
+(`LAYER_START/LAYER_END`, Worker1.py:27-28 = [0,11), Worker2.py:26-27 = [11,22)) and keeps
+embedding, final norm and lm_head on the orchestrator (orchestration.py:45-47).  Here the
+first stage owns the embedding, the last stage owns final norm + lm_head + sampler, and the
+layer ranges are either given explicitly, split evenly (which reproduces 11/11 for 22
+layers), or balanced by weight-bytes so that the lm_head (≈2.4 decoder layers' worth of
+weight traffic for Llama-3-8B) does not make the last stage the bottleneck.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+from .spec import ModelSpec
+
+
+@dataclass(frozen=True)
+class StagePlan:
+    stage: int
+    num_stages: int
+    layer_start: int          # half-open [layer_start, layer_end), as in the reference
+    layer_end: int
+    has_embed: bool
+    has_head: bool
+
+    @property
+    def num_layers(self) -> int:
+        return self.layer_end - self.layer_start
+
+    @property
+    def layers(self) -> range:
+        return range(self.layer_start, self.layer_end)
+
+    def describe(self) -> str:
+        # same "start-end" spelling the reference's worker /health uses (Worker1.py:204)
+        return f"{self.layer_start}-{self.layer_end}"
+
+
+def even_split(num_layers: int, num_stages: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges whose sizes differ by at most one; earlier stages get the extras."""
+    if num_stages < 1:
+        raise ValueError("num_stages must be >= 1")
+    if num_stages > num_layers:
+        raise ValueError(f"cannot split {num_layers} layers into {num_stages} stages")
+    base, extra = divmod(num_layers, num_stages)
+    out, start = [], 0
+    for s in range(num_stages):
+        n = base + (1 if s < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+def balanced_split(spec: ModelSpec, num_stages: int) -> List[Tuple[int, int]]:
+    """Minimise the heaviest stage, counting the decode-time weight traffic of each part.
+
+    Cost unit = one decoder layer.  The last stage additionally streams the lm_head matrix
+    every step; the embedding is a row gather and costs ~nothing.  Exact DP over contiguous
+    splits (L ≤ a few hundred, P ≤ 8: trivial).
+    """
+    L = spec.num_layers
+    if num_stages == 1:
+        return [(0, L)]
+    if num_stages > L:
+        raise ValueError(f"cannot split {L} layers into {num_stages} stages")
+    head_cost = spec.head_param_count() / spec.layer_param_count()
+    INF = float("inf")
+    # best[s][i]: minimal max-cost of splitting layers [0,i) into s stages (all non-empty)
+    best = [[INF] * (L + 1) for _ in range(num_stages + 1)]
+    cut = [[-1] * (L + 1) for _ in range(num_stages + 1)]
+    best[0][0] = 0.0
+    for s in range(1, num_stages + 1):
+        last = s == num_stages
+        for i in range(s, L + 1):
+            if last and i != L:
+                continue
+            for j in range(s - 1, i):
+                if best[s - 1][j] == INF:
+                    continue
+                c = (i - j) + (head_cost if last else 0.0)
+                v = max(best[s - 1][j], c)
+                # strict '<' keeps the earliest cut => earlier stages take the extra layers
+                if v < best[s][i] - 1e-12:
+                    best[s][i] = v
+                    cut[s][i] = j
+    bounds, i = [], L
+    for s in range(num_stages, 0, -1):
+        j = cut[s][i]
+        bounds.append((j, i))
+        i = j
+    bounds.reverse()
+    return bounds
+
+
+def make_plans(spec: ModelSpec, num_stages: int, mode: str = "balanced",
+               ranges: Optional[Sequence[Tuple[int, int]]] = None) -> List[StagePlan]:
+    """Stage plans for `num_stages` stages.
+
+    mode: "even" | "balanced" | "explicit" (with `ranges`).  Explicit ranges must tile
+    [0, num_layers) contiguously with non-empty half-open intervals.
+    """
+    if ranges is not None:
+        mode = "explicit"
+    if mode == "explicit":
+        if ranges is None or len(ranges) != num_stages:
+            raise ValueError("explicit partition needs one (start,end) range per stage")
+        pos = 0
+        for (a, b) in ranges:
+            if a != pos or b <= a:
+                raise ValueError(f"ranges must tile [0,{spec.num_layers}) contiguously, got {list(ranges)}")
+            pos = b
+        if pos != spec.num_layers:
+            raise ValueError(f"ranges cover [0,{pos}) but the model has {spec.num_layers} layers")
+        bounds = [tuple(r) for r in ranges]
+    elif mode == "even":
+        bounds = even_split(spec.num_layers, num_stages)
+    elif mode == "balanced":
+        bounds = balanced_split(spec, num_stages)
+    else:
+        raise ValueError(f"unknown partition mode {mode!r}")
+    return [StagePlan(stage=s, num_stages=num_stages, layer_start=a, layer_end=b,
+                      has_embed=(s == 0), has_head=(s == num_stages - 1))
+            for s, (a, b) in enumerate(bounds)]

@@ -1,0 +1,286 @@
+// Causal GQA attention over the paged, fragment-ordered KV cache (kv_layout.h).
+//
+// One kernel serves chunked prefill and single-token decode: a work item is
+// (sequence b, kv head, query tile, kv split) and is owned by ONE wave — no LDS, no barriers.
+// The wave's MFMA columns are "query columns" c = (position-in-tile, head-in-GQA-group): all
+// query heads that share a kv head ride in the same MFMA, so K/V are read once per group.
+//
+// Per 32-token block (both MFMAs are v_mfma_f32_16x16x32_bf16):
+//   S^T[key, c]  = K[key, :] . Q[c, :]          A = K fragment (1 KiB coalesced load, as stored)
+//                                               B = Q fragment (registers, loaded once)
+//   online softmax down each column — the column lives in one lane's registers (+ the other
+//   three lane quads), so max/sum need two shuffles, not a 16-lane tree
+//   O^T[d, c]   += V^T[d, key] . P^T[key, c]    A = V fragment (as stored, key order permuted
+//                                               to match), B = P^T = the S^T accumulator
+//                                               registers packed to bf16, no data movement
+//
+// Split-KV (decode with few sequences / long contexts): each split writes unnormalised
+// (m, l, O) per column and a second kernel merges them.
+//
+// Replaces HF SDPA inside LlamaDecoderLayer, which the reference runs over the full S x S
+// problem on every step with no cache (Worker1.py:128-137, use_cache=False).
+#include "common.h"
+#include "kv_layout.h"
+#include "launch.h"
+
+namespace dlia {
+
+struct AttnParams {
+  bf16* out; long ldo;            // [T, Hq*D]
+  const bf16* q; long ldq;        // q rows (post-RoPE) inside the fused qkv activation
+  const bf16* kv;                 // this layer's cache
+  const int* q_start;             // [B+1] first token row of each sequence's chunk
+  const int* ctx_lens;            // [B] tokens already cached before this chunk
+  const int* block_table;         // [B, max_blocks]
+  float* partial;                 // split-KV partials
+  int B, Hq, Hkv, g_shift;        // group size g = 1 << g_shift
+  int max_blocks, num_blocks, qtiles, splits;
+  float scale_log2;               // softmax scale * log2(e)
+};
+
+constexpr float kNegInf = -__builtin_inff();
+
+template <int D, int NT>
+__global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
+  constexpr int KS = D / 32;      // MFMA k-steps over the head dim (QK^T)
+  constexpr int DT = D / 16;      // 16-row tiles of the head dim (PV)
+  constexpr int NC = NT * 16;     // query columns per wave
+  const int lane = threadIdx.x & 63, l15 = lane & 15, quad = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  long item = (long)blockIdx.x * 4 + wave;
+  const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
+  if (item >= nitems) return;
+  const int split = (int)(item % p.splits); item /= p.splits;
+  const int qtile = (int)(item % p.qtiles); item /= p.qtiles;
+  const int kvh = (int)(item % p.Hkv);
+  const int b = (int)(item / p.Hkv);
+
+  const int g = 1 << p.g_shift;
+  const int QT = NC >> p.g_shift;                 // query positions per tile
+  const int t0 = p.q_start[b];
+  const int q_len = p.q_start[b + 1] - t0;
+  const int ctx = p.ctx_lens[b];
+  const int qp0 = qtile * QT;
+  const bool tile_live = qp0 < q_len;             // wave-uniform
+
+  // column bookkeeping: lane's column within tile nt is c = nt*16 + l15
+  int col_qpos[NT];       // position within the chunk, or -1 when the column is padding
+  long col_row[NT];       // element offset of the column's q row / out row base (without ld)
+  int col_head[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = nt * 16 + l15;
+    const int pl = c >> p.g_shift, hl = c & (g - 1);
+    const int qp = qp0 + pl;
+    col_qpos[nt] = (tile_live && qp < q_len) ? qp : -1;
+    col_row[nt] = (long)(t0 + (qp < q_len ? qp : 0));
+    col_head[nt] = kvh * g + hl;
+  }
+
+  // kv block range of this split
+  const int tile_q_end = min(q_len, qp0 + QT);
+  const int kv_len = tile_live ? ctx + tile_q_end : 0;
+  const int nb = (kv_len + kBlockTokens - 1) / kBlockTokens;
+  const int per = (nb + p.splits - 1) / p.splits;
+  const int kb0 = split * per, kb1 = min(nb, kb0 + per);
+
+  // Q fragments (B operand): lane (c, quad) holds Q[c][s*32 + quad*8 .. +8]
+  u32x4 qf[NT][KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (col_qpos[nt] >= 0)
+        qf[nt][s] = ld16(p.q + col_row[nt] * p.ldq + col_head[nt] * D + s * 32 + quad * 8);
+      else
+        qf[nt][s] = u32x4{0, 0, 0, 0};
+    }
+
+  f32x4 o[DT][NT];
+  float m[NT], l[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    m[nt] = kNegInf; l[nt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const long slab = kv_slab_elems(D);
+  for (int kb = kb0; kb < kb1; ++kb) {
+    int blk = p.block_table[(long)b * p.max_blocks + kb];
+    blk = (blk >= 0 && blk < p.num_blocks) ? blk : 0;          // never a wild read
+    const bf16* kbase = p.kv + kv_head_base(blk, kvh, p.Hkv, D, 0) + lane * 8;
+    const bf16* vbase = kbase + slab;
+    u32x4 kf[2][KS], vf[DT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kf[kt][s] = ld16(kbase + kt * 16 * D + s * 512);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld16(vbase + dt * 512);
+
+    // S^T = K Q^T : st[kt][nt][r] = score(key = kb*32 + kt*16 + quad*4 + r, column nt*16+l15)
+    f32x4 st[2][NT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a = mfma16(kf[kt][s], qf[nt][s], a);
+        st[kt][nt] = a;
+      }
+
+    u32x4 pf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int limit = col_qpos[nt] >= 0 ? ctx + col_qpos[nt] : -1;   // last visible key position
+      float mx = kNegInf;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kpos = kb * kBlockTokens + kt * 16 + quad * 4 + r;
+          const float s = kpos <= limit ? st[kt][nt][r] : kNegInf;
+          st[kt][nt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m[nt], mx);
+      const float m_safe = m_new == kNegInf ? 0.f : m_new;
+      const float alpha = exp2f((m[nt] - m_safe) * p.scale_log2);     // m = -inf -> 0
+      m[nt] = m_new;
+      float pv[8], rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f((st[kt][nt][r] - m_safe) * p.scale_log2);
+          pv[kt * 4 + r] = e;
+          rs += e;
+        }
+      l[nt] = l[nt] * alpha + rs;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt][nt] *= alpha;
+      pf[nt] = pack8(pv);     // element j: key 16*(j>>2) + 4*quad + (j&3) — the V slab's key order
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[dt][nt] = mfma16(vf[dt], pf[nt], o[dt][nt]);
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float lt = l[nt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    if (col_qpos[nt] < 0) continue;
+    if (p.splits == 1) {
+      const float inv = lt > 0.f ? 1.f / lt : 0.f;
+      bf16* orow = p.out + col_row[nt] * p.ldo + col_head[nt] * D + quad * 4;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        u32x2 v = {pack_bf16(o[dt][nt][0] * inv, o[dt][nt][1] * inv),
+                   pack_bf16(o[dt][nt][2] * inv, o[dt][nt][3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + dt * 16) = v;
+      }
+    } else {
+      // record = [m, l, pad, pad, O[D]] fp32 per (item, column)
+      const long rec = ((((long)b * p.Hkv + kvh) * p.qtiles + qtile) * p.splits + split) * NC + nt * 16 + l15;
+      float* r = p.partial + rec * (D + 4);
+      if (quad == 0) { r[0] = m[nt]; r[1] = lt; }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(r + 4 + dt * 16 + quad * 4) = o[dt][nt];
+    }
+  }
+}
+
+// Merge split-KV partials. One workgroup per (b, kv head, query tile); thread -> (column, 4 dims).
+template <int D, int NT>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+  constexpr int NC = NT * 16;
+  long item = blockIdx.x;
+  const int qtile = (int)(item % p.qtiles); item /= p.qtiles;
+  const int kvh = (int)(item % p.Hkv);
+  const int b = (int)(item / p.Hkv);
+  const int g = 1 << p.g_shift;
+  const int QT = NC >> p.g_shift;
+  const int t0 = p.q_start[b];
+  const int q_len = p.q_start[b + 1] - t0;
+  const long rec0 = (((long)b * p.Hkv + kvh) * p.qtiles + qtile) * p.splits * NC;
+  for (int w = threadIdx.x; w < NC * (D / 4); w += 256) {
+    const int c = w / (D / 4), d4 = (w - c * (D / 4)) * 4;
+    const int qp = qtile * QT + (c >> p.g_shift);
+    if (qp >= q_len) continue;
+    float mt = kNegInf;
+    for (int s = 0; s < p.splits; ++s) mt = fmaxf(mt, p.partial[(rec0 + (long)s * NC + c) * (D + 4)]);
+    float lt = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (mt != kNegInf) {
+      for (int s = 0; s < p.splits; ++s) {
+        const float* r = p.partial + (rec0 + (long)s * NC + c) * (D + 4);
+        const float ms = r[0];
+        if (ms == kNegInf) continue;
+        const float wgt = exp2f((ms - mt) * p.scale_log2);
+        lt += r[1] * wgt;
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(r + 4 + d4);
+        acc += ov * wgt;
+      }
+    }
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    const int head = kvh * g + (c & (g - 1));
+    u32x2 v = {pack_bf16(acc[0] * inv, acc[1] * inv), pack_bf16(acc[2] * inv, acc[3] * inv)};
+    *reinterpret_cast<u32x2*>(p.out + (long)(t0 + qp) * p.ldo + head * D + d4) = v;
+  }
+}
+
+template <int D, int NT>
+static void launch_attn(const AttnParams& p, hipStream_t stream) {
+  const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
+  hipLaunchKernelGGL((paged_attn_kernel<D, NT>), dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p);
+  if (p.splits > 1)
+    hipLaunchKernelGGL((attn_combine_kernel<D, NT>), dim3((unsigned)((long)p.B * p.Hkv * p.qtiles)), dim3(256), 0,
+                       stream, p);
+}
+
+}  // namespace dlia
+
+using namespace dlia;
+
+// Number of query columns per wave the launcher uses for a given chunk length.
+static inline int attn_nt(int max_q_len, int g) { return (max_q_len * g > 16) ? 2 : 1; }
+
+extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) {
+  if (splits <= 1) return 0;
+  const int g = Hq / Hkv;
+  const int nt = attn_nt(max_q_len, g);
+  const int qt = (nt * 16) / g;
+  const long qtiles = (max_q_len + qt - 1) / qt;
+  return (long)B * Hkv * qtiles * splits * nt * 16 * (D + 4);
+}
+
+extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache,
+                                     const int* q_start, const int* ctx_lens, const int* block_table,
+                                     float* partial, int B, int max_q_len, int Hq, int Hkv, int D,
+                                     int max_blocks, int num_blocks, long ldq, long ldo, float scale,
+                                     int splits, hipStream_t stream) {
+  if (B <= 0 || max_q_len <= 0) return;
+  AttnParams p;
+  p.out = (bf16*)out; p.ldo = ldo; p.q = (const bf16*)qkv; p.ldq = ldq; p.kv = (const bf16*)kv_cache;
+  p.q_start = q_start; p.ctx_lens = ctx_lens; p.block_table = block_table; p.partial = partial;
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv;
+  const int g = Hq / Hkv;
+  int gs = 0;
+  while ((1 << gs) < g) ++gs;
+  p.g_shift = gs;
+  p.max_blocks = max_blocks; p.num_blocks = num_blocks;
+  p.splits = (splits > 1 && partial) ? splits : 1;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  const int nt = attn_nt(max_q_len, g);
+  const int qt = (nt * 16) / g;
+  p.qtiles = (max_q_len + qt - 1) / qt;
+  if (D == 128) { if (nt == 1) launch_attn<128, 1>(p, stream); else launch_attn<128, 2>(p, stream); }
+  else if (D == 64) { if (nt == 1) launch_attn<64, 1>(p, stream); else launch_attn<64, 2>(p, stream); }
+}

@@ -1,0 +1,274 @@
+// torch custom-op bindings for the HIP kernel library (namespace `dlia`).
+// Every op validates shapes / dtypes / devices on the host before launching: a kernel that
+// indexes out of bounds can take the whole GPU down, so nothing reaches a launch unchecked.
+// All launches go to PyTorch's current HIP stream, which makes them capturable in a hipGraph
+// through torch.cuda.graph().
+#include <torch/library.h>
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/util/Optional.h>
+
+#include "launch.h"
+
+extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits);
+
+namespace {
+
+using at::Tensor;
+using OptTensor = const std::optional<Tensor>&;
+
+inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
+
+#define DLIA_CHECK(cond, ...) TORCH_CHECK(cond, "dlia: ", __VA_ARGS__)
+
+inline void check_dev(const Tensor& t, const char* name) {
+  DLIA_CHECK(t.is_cuda(), name, " must be a GPU tensor");
+}
+inline void check_bf16(const Tensor& t, const char* name) {
+  check_dev(t, name);
+  DLIA_CHECK(t.scalar_type() == at::kBFloat16, name, " must be bfloat16");
+}
+inline void check_i32(const Tensor& t, const char* name) {
+  check_dev(t, name);
+  DLIA_CHECK(t.scalar_type() == at::kInt && t.is_contiguous(), name, " must be contiguous int32");
+}
+inline void check_f32(const Tensor& t, const char* name) {
+  check_dev(t, name);
+  DLIA_CHECK(t.scalar_type() == at::kFloat && t.is_contiguous(), name, " must be contiguous float32");
+}
+inline void check_rows(const Tensor& t, const char* name) {
+  DLIA_CHECK(t.dim() == 2 && t.stride(1) == 1, name, " must be 2-D with unit inner stride");
+  DLIA_CHECK(t.stride(0) % 8 == 0, name, " row stride must be a multiple of 8 elements (16-byte rows)");
+  DLIA_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, " must be 16-byte aligned");
+}
+
+// out[r,:] = norm(x[row_idx[r] or r,:] (+delta -> x)) * w (+ b)
+void norm(Tensor out, Tensor x, OptTensor delta, const Tensor& w, OptTensor b, OptTensor row_idx,
+          double eps, bool layernorm) {
+  check_bf16(out, "out"); check_bf16(x, "x"); check_bf16(w, "w");
+  check_rows(out, "out"); check_rows(x, "x");
+  const int64_t H = x.size(1);
+  DLIA_CHECK(H % 8 == 0, "hidden size must be a multiple of 8");
+  DLIA_CHECK(out.size(1) == H && w.numel() == H && w.is_contiguous(), "norm: shape mismatch");
+  const int* ridx = nullptr;
+  int64_t rows = x.size(0);
+  if (row_idx.has_value()) {
+    check_i32(*row_idx, "row_idx");
+    rows = row_idx->numel();
+    ridx = row_idx->data_ptr<int>();
+  }
+  DLIA_CHECK(out.size(0) >= rows, "norm: out has too few rows");
+  const void* dp = nullptr;
+  if (delta.has_value()) {
+    check_bf16(*delta, "delta"); check_rows(*delta, "delta");
+    DLIA_CHECK(delta->sizes() == x.sizes() && delta->stride(0) == x.stride(0), "delta must match x");
+    dp = delta->data_ptr();
+  }
+  const void* bp = nullptr;
+  if (layernorm) {
+    DLIA_CHECK(b.has_value(), "layernorm needs a bias");
+    check_bf16(*b, "b");
+    DLIA_CHECK(b->numel() == H && b->is_contiguous(), "bias shape");
+    bp = b->data_ptr();
+  }
+  dlia_norm(out.data_ptr(), x.data_ptr(), dp, w.data_ptr(), bp, ridx, (int)rows, (int)H, x.stride(0),
+            out.stride(0), (float)eps, layernorm ? 1 : 0, cur_stream());
+}
+
+void embed(Tensor out, const Tensor& ids, OptTensor pos, const Tensor& wte, OptTensor wpe) {
+  check_bf16(out, "out"); check_bf16(wte, "wte"); check_i32(ids, "ids");
+  DLIA_CHECK(out.is_contiguous() && wte.is_contiguous() && wte.dim() == 2, "embed: contiguous 2-D tables");
+  const int64_t T = ids.numel(), H = wte.size(1);
+  DLIA_CHECK(out.dim() == 2 && out.size(0) >= T && out.size(1) == H && H % 8 == 0, "embed: out shape");
+  const void* wp = nullptr; const int* pp = nullptr; int maxp = 0;
+  if (wpe.has_value()) {
+    check_bf16(*wpe, "wpe");
+    DLIA_CHECK(pos.has_value(), "wpe needs positions");
+    check_i32(*pos, "pos");
+    DLIA_CHECK(pos->numel() >= T && wpe->is_contiguous() && wpe->size(1) == H, "embed: wpe/pos shape");
+    wp = wpe->data_ptr(); pp = pos->data_ptr<int>(); maxp = (int)wpe->size(0);
+  }
+  dlia_embed(out.data_ptr(), ids.data_ptr<int>(), pp, wte.data_ptr(), wp, (int)T, (int)H, (int)wte.size(0),
+             maxp, cur_stream());
+}
+
+struct KvGeom { int64_t num_blocks; };
+inline KvGeom check_kv(const Tensor& kv, int64_t Hkv, int64_t D) {
+  check_bf16(kv, "kv_cache");
+  DLIA_CHECK(kv.is_contiguous() && kv.dim() == 4 && kv.size(1) == Hkv && kv.size(2) == 2 && kv.size(3) == 32 * D,
+             "kv_cache must be [num_blocks, Hkv, 2, 32*D]");
+  return {kv.size(0)};
+}
+
+void rope_kvwrite(Tensor qkv, Tensor kv_cache, const Tensor& cos_t, const Tensor& sin_t,
+                  const Tensor& tok_pos, const Tensor& tok_seq, const Tensor& block_table,
+                  int64_t Hq, int64_t Hkv, int64_t D, bool use_rope) {
+  check_bf16(qkv, "qkv");
+  DLIA_CHECK(qkv.dim() == 2 && qkv.is_contiguous() && qkv.size(1) == (Hq + 2 * Hkv) * D, "qkv must be [T,(Hq+2Hkv)*D]");
+  DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
+  const int64_t T = qkv.size(0);
+  auto g = check_kv(kv_cache, Hkv, D);
+  check_i32(tok_pos, "tok_pos"); check_i32(tok_seq, "tok_seq"); check_i32(block_table, "block_table");
+  DLIA_CHECK(tok_pos.numel() >= T && tok_seq.numel() >= T && block_table.dim() == 2, "rope_kvwrite: metadata shapes");
+  int rope_len = 1;
+  const float* cp = nullptr; const float* sp = nullptr;
+  if (use_rope) {
+    check_f32(cos_t, "cos"); check_f32(sin_t, "sin");
+    DLIA_CHECK(cos_t.dim() == 2 && cos_t.size(1) == D / 2 && sin_t.sizes() == cos_t.sizes(), "rope tables [P, D/2]");
+    rope_len = (int)cos_t.size(0); cp = cos_t.data_ptr<float>(); sp = sin_t.data_ptr<float>();
+  }
+  // tok_seq values index block_table rows: the caller guarantees tok_seq < block_table.size(0)
+  dlia_rope_kvwrite(qkv.data_ptr(), kv_cache.data_ptr(), cp, sp, tok_pos.data_ptr<int>(), tok_seq.data_ptr<int>(),
+                    block_table.data_ptr<int>(), (int)T, (int)Hq, (int)Hkv, (int)D, (int)block_table.size(1),
+                    (int)g.num_blocks, rope_len, use_rope ? 1 : 0, cur_stream());
+}
+
+// out[M, N_out] = epi(x[M,K] @ W^T); wp = packed weights (uint8 view of the packed image).
+// epi: 0 none, 1 +bias, 2 +residual, 3 +bias+residual, 4 swiglu, 5 +bias -> gelu_tanh.
+void gemm(Tensor out, const Tensor& x, const Tensor& wp, OptTensor bias, OptTensor residual,
+          OptTensor workspace, int64_t N, int64_t epi, int64_t splitk) {
+  check_bf16(x, "x"); check_rows(x, "x"); check_dev(out, "out"); check_dev(wp, "wp");
+  const int64_t M = x.size(0), K = x.size(1);
+  DLIA_CHECK(K % 128 == 0, "K must be a multiple of 128");
+  DLIA_CHECK(N % 4 == 0, "N must be a multiple of 4");
+  DLIA_CHECK(epi >= 0 && epi <= 5, "bad epilogue");
+  const int64_t n_pad = (N + 127) / 128 * 128;
+  DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == n_pad * K * 2,
+             "packed weight has ", wp.numel() * wp.element_size(), " bytes, expected ", n_pad * K * 2);
+  DLIA_CHECK(reinterpret_cast<uintptr_t>(wp.data_ptr()) % 16 == 0, "packed weight alignment");
+  const int64_t n_out = epi == 4 ? N / 2 : N;
+  if (epi == 4) DLIA_CHECK(N % 32 == 0, "swiglu needs gate/up tile pairs");
+  const bool f32 = out.scalar_type() == at::kFloat;
+  DLIA_CHECK(f32 || out.scalar_type() == at::kBFloat16, "out must be bf16 or fp32");
+  DLIA_CHECK(out.dim() == 2 && out.stride(1) == 1 && out.size(0) >= M && out.size(1) >= n_out, "out shape");
+  DLIA_CHECK(out.stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0, "out alignment");
+  const void* bp = nullptr; const void* rp = nullptr; long ldr = 0;
+  if (epi == 1 || epi == 3 || epi == 5) {
+    DLIA_CHECK(bias.has_value(), "epilogue needs bias");
+    check_bf16(*bias, "bias");
+    DLIA_CHECK(bias->is_contiguous() && bias->numel() >= n_out, "bias shape");
+    bp = bias->data_ptr();
+  }
+  if (epi == 2 || epi == 3) {
+    DLIA_CHECK(residual.has_value(), "epilogue needs residual");
+    check_bf16(*residual, "residual"); check_rows(*residual, "residual");
+    DLIA_CHECK(residual->size(0) >= M && residual->size(1) >= n_out, "residual shape");
+    rp = residual->data_ptr(); ldr = residual->stride(0);
+  }
+  auto stream = cur_stream();
+  if (M <= 64) {
+    float* ws = nullptr;
+    int sk = (int)splitk;
+    if (sk <= 0) sk = dlia_gemm_skinny_splitk((int)M, (int)N, (int)K);
+    if (workspace.has_value() && sk > 1) {
+      check_f32(*workspace, "workspace");
+      const int64_t have = workspace->numel();
+      while (sk > 1 && have < (int64_t)sk * M * N) sk /= 2;      // shrink rather than overrun
+      ws = workspace->data_ptr<float>();
+    } else {
+      sk = 1;
+    }
+    dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, ws, nullptr, (int)M, (int)N, (int)K,
+                     x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, stream);
+  } else {
+    dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
+                   out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
+  }
+}
+
+int64_t gemm_splitk(int64_t M, int64_t N, int64_t K) { return dlia_gemm_skinny_splitk((int)M, (int)N, (int)K); }
+
+int64_t attention_ws_floats(int64_t B, int64_t max_q_len, int64_t Hq, int64_t Hkv, int64_t D, int64_t splits) {
+  return dlia_paged_attention_ws_floats((int)B, (int)max_q_len, (int)Hq, (int)Hkv, (int)D, (int)splits);
+}
+
+void paged_attention(Tensor out, const Tensor& qkv, const Tensor& kv_cache, const Tensor& q_start,
+                     const Tensor& ctx_lens, const Tensor& block_table, OptTensor partial,
+                     int64_t max_q_len, int64_t Hq, int64_t Hkv, int64_t D, double scale, int64_t splits) {
+  check_bf16(out, "out"); check_bf16(qkv, "qkv"); check_rows(out, "out"); check_rows(qkv, "qkv");
+  DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
+  DLIA_CHECK(Hq % Hkv == 0, "Hq must be a multiple of Hkv");
+  const int64_t g = Hq / Hkv;
+  DLIA_CHECK(g == 1 || g == 2 || g == 4 || g == 8 || g == 16, "GQA group size must be a power of two <= 16");
+  DLIA_CHECK(qkv.size(1) >= Hq * D && out.size(1) >= Hq * D, "qkv/out width");
+  auto geo = check_kv(kv_cache, Hkv, D);
+  check_i32(q_start, "q_start"); check_i32(ctx_lens, "ctx_lens"); check_i32(block_table, "block_table");
+  const int64_t B = ctx_lens.numel();
+  DLIA_CHECK(q_start.numel() == B + 1 && block_table.dim() == 2 && block_table.size(0) >= B, "attention metadata shapes");
+  float* pp = nullptr;
+  int sp = (int)splits;
+  if (sp > 1) {
+    DLIA_CHECK(partial.has_value(), "split-KV needs a partial workspace");
+    check_f32(*partial, "partial");
+    const int64_t need = dlia_paged_attention_ws_floats((int)B, (int)max_q_len, (int)Hq, (int)Hkv, (int)D, sp);
+    DLIA_CHECK(partial->numel() >= need, "partial workspace too small: ", partial->numel(), " < ", need);
+    pp = partial->data_ptr<float>();
+  } else {
+    sp = 1;
+  }
+  // The caller guarantees: q_start is non-decreasing with q_start[B] <= rows of qkv/out, chunk
+  // lengths <= max_q_len, and ctx_lens[b] + q_len[b] <= 32 * block_table.size(1).
+  dlia_paged_attention(out.data_ptr(), qkv.data_ptr(), kv_cache.data_ptr(), q_start.data_ptr<int>(),
+                       ctx_lens.data_ptr<int>(), block_table.data_ptr<int>(), pp, (int)B, (int)max_q_len, (int)Hq,
+                       (int)Hkv, (int)D, (int)block_table.size(1), (int)geo.num_blocks, qkv.stride(0),
+                       out.stride(0), (float)scale, sp, cur_stream());
+}
+
+void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, const Tensor& top_k,
+            const Tensor& top_p, const Tensor& seeds, const Tensor& steps, int64_t vocab,
+            OptTensor dbg_probs, OptTensor dbg_ids) {
+  check_i32(out_tokens, "out_tokens"); check_dev(logits, "logits");
+  DLIA_CHECK(logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1, "logits must be fp32 [R, >=vocab]");
+  const int64_t R = logits.size(0);
+  DLIA_CHECK(vocab > 0 && vocab <= logits.size(1), "vocab out of range");
+  check_f32(temperature, "temperature"); check_i32(top_k, "top_k"); check_f32(top_p, "top_p"); check_i32(steps, "steps");
+  check_dev(seeds, "seeds");
+  DLIA_CHECK(seeds.scalar_type() == at::kLong && seeds.is_contiguous(), "seeds must be int64");
+  DLIA_CHECK(out_tokens.numel() >= R && temperature.numel() >= R && top_k.numel() >= R && top_p.numel() >= R &&
+             seeds.numel() >= R && steps.numel() >= R, "per-row sampling parameter shapes");
+  float* dp = nullptr; int* di = nullptr; int cap = 0;
+  if (dbg_probs.has_value()) {
+    DLIA_CHECK(dbg_ids.has_value(), "dbg_probs needs dbg_ids");
+    check_f32(*dbg_probs, "dbg_probs"); check_i32(*dbg_ids, "dbg_ids");
+    DLIA_CHECK(dbg_probs->dim() == 2 && dbg_probs->size(0) >= R && dbg_ids->sizes() == dbg_probs->sizes(), "dbg shapes");
+    dp = dbg_probs->data_ptr<float>(); di = dbg_ids->data_ptr<int>(); cap = (int)dbg_probs->size(1);
+    DLIA_CHECK(cap <= 1024, "dbg capacity <= 1024");
+  }
+  dlia_sample(out_tokens.data_ptr<int>(), logits.data_ptr<float>(), temperature.data_ptr<float>(),
+              top_k.data_ptr<int>(), top_p.data_ptr<float>(), reinterpret_cast<const uint64_t*>(seeds.data_ptr<int64_t>()),
+              steps.data_ptr<int>(), (int)R, (int)vocab, logits.stride(0), dp, di, cap, cur_stream());
+}
+
+void advance(Tensor x, int64_t delta) {
+  check_i32(x, "x");
+  dlia_advance_i32(x.data_ptr<int>(), (int)x.numel(), (int)delta, cur_stream());
+}
+
+}  // namespace
+
+TORCH_LIBRARY(dlia, m) {
+  m.def("norm(Tensor(a!) out, Tensor(b!) x, Tensor? delta, Tensor w, Tensor? b, Tensor? row_idx, float eps, bool layernorm) -> ()");
+  m.def("embed(Tensor(a!) out, Tensor ids, Tensor? pos, Tensor wte, Tensor? wpe) -> ()");
+  m.def("rope_kvwrite(Tensor(a!) qkv, Tensor(b!) kv_cache, Tensor cos, Tensor sin, Tensor tok_pos, Tensor tok_seq, Tensor block_table, int Hq, int Hkv, int D, bool use_rope) -> ()");
+  m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk) -> ()");
+  m.def("gemm_splitk(int M, int N, int K) -> int");
+  m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
+  m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
+  m.def("sample(Tensor(a!) out_tokens, Tensor logits, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
+  m.def("advance(Tensor(a!) x, int delta) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
+  m.impl("norm", &norm);
+  m.impl("embed", &embed);
+  m.impl("rope_kvwrite", &rope_kvwrite);
+  m.impl("gemm", &gemm);
+  m.impl("paged_attention", &paged_attention);
+  m.impl("sample", &sample);
+  m.impl("advance", &advance);
+}
+
+TORCH_LIBRARY_IMPL(dlia, CompositeExplicitAutograd, m) {
+  m.impl("gemm_splitk", &gemm_splitk);
+  m.impl("attention_ws_floats", &attention_ws_floats);
+}

@@ -1,0 +1,93 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of this engine.
+// Wavefronts are 64 lanes; every kernel here is written for that width.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dlia {
+
+constexpr int kWave = 64;
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// wave-wide reductions (all 64 lanes end with the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block reductions through LDS; `scratch` must hold >= 16 floats. blockDim.x multiple of 64.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane_id() == 0) scratch[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += scratch[i];
+  return r;
+}
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+// streamed-once data (weights in decode): non-temporal so it does not displace reusable lines
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  bf16x2 v = {(bf16)a, (bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void unpack8(u32x4 v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_lo(v[i]); f[2 * i + 1] = bf16_hi(v[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+// GPT-2 "gelu_new": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float e = __expf(2.f * u);           // tanh(u) = 1 - 2/(e^{2u}+1)
+  const float t = 1.f - 2.f / (e + 1.f);
+  return 0.5f * x * (1.f + t);
+}
+
+// Bijective XCD-aware remap of a linear block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so giving each residue class a contiguous chunk of the logical grid keeps
+// neighbouring tiles (which share operand panels) in one XCD's L2. Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7, i = bid >> 3;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + i;
+}
+
+}  // namespace dlia

@@ -1,0 +1,67 @@
+// C launch entry points of the HIP kernel library. The kernels are compiled without any
+// PyTorch headers; bindings.cpp wraps these in torch custom ops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+extern "C" {
+
+// ---- norm.hip -------------------------------------------------------------------------
+// out[r,:] = norm(x[row_idx ? row_idx[r] : r,:] (+ delta, written back into x)) * w (+ b)
+void dlia_norm(void* out, void* x, const void* delta, const void* w, const void* b,
+               const int* row_idx, int rows, int H, long ldx, long ldo, float eps,
+               int layernorm, hipStream_t stream);
+
+// ---- embed.hip ------------------------------------------------------------------------
+// out[t,:] = wte[ids[t],:] (+ wpe[pos[t],:])
+void dlia_embed(void* out, const int* ids, const int* pos, const void* wte, const void* wpe,
+                int T, int H, int vocab, int max_pos, hipStream_t stream);
+
+// ---- rope_kv.hip ----------------------------------------------------------------------
+// RoPE on the q and k slices of a fused qkv activation (in place on q), and scatter of the
+// (rotated) k and v rows into the paged, MFMA-fragment-ordered KV cache.
+void dlia_rope_kvwrite(void* qkv, void* kv_cache, const float* cos_t, const float* sin_t,
+                       const int* tok_pos, const int* tok_seq, const int* block_table,
+                       int T, int Hq, int Hkv, int D, int max_blocks, int num_blocks,
+                       int rope_len, int use_rope, hipStream_t stream);
+
+// ---- gemm_skinny.hip ------------------------------------------------------------------
+// out[M,N] = epilogue(x[M,K] @ Wp^T), M <= 64 per call (weight-streaming regime).
+// epi: 0 none, 1 +bias, 2 +residual, 3 +bias+residual, 4 swiglu (interleaved gate/up tiles,
+// N = 2*N_out), 5 +bias then gelu_tanh. out_f32: write fp32 instead of bf16.
+void dlia_gemm_skinny(void* out, const void* x, const void* wp, const void* bias,
+                      const void* residual, float* workspace, unsigned* counters,
+                      int M, int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32,
+                      int splitk, hipStream_t stream);
+// heuristic split-K factor the launcher would choose (so callers can size the workspace)
+int dlia_gemm_skinny_splitk(int M, int N, int K);
+
+// ---- gemm_tile.hip --------------------------------------------------------------------
+// Same contract for large M (prefill): 128x128x64 LDS-staged MFMA tiles.
+void dlia_gemm_tile(void* out, const void* x, const void* wp, const void* bias,
+                    const void* residual, int M, int N, int K, long ldx, long ldo, long ldr,
+                    int epi, int out_f32, hipStream_t stream);
+
+// ---- attention.hip --------------------------------------------------------------------
+// Causal GQA attention of ragged query chunks against the paged KV cache (prefill chunks and
+// single-token decode are the same kernel). Work items are (sequence, kv head, query tile,
+// kv split); `partial` holds split-KV partials when splits > 1.
+void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache,
+                          const int* q_start, const int* ctx_lens, const int* block_table,
+                          float* partial, int B, int max_q_len, int Hq, int Hkv, int D,
+                          int max_blocks, int num_blocks, long ldq, long ldo, float scale,
+                          int splits, hipStream_t stream);
+long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits);
+
+// ---- sampler.hip ----------------------------------------------------------------------
+// One token per row from fp32 logits [R, ldl] with temperature / top-k / top-p and a
+// counter-based RNG keyed by (seed[r], step[r]); temperature <= 0 -> argmax.
+void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
+                 const int* top_k, const float* top_p, const uint64_t* seeds,
+                 const int* steps, int R, int vocab, long ldl, float* dbg_probs,
+                 int* dbg_ids, int dbg_cap, hipStream_t stream);
+
+// ---- misc.hip -------------------------------------------------------------------------
+void dlia_advance_i32(int* x, int n, int delta, hipStream_t stream);
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// Token sampling on device: temperature -> top-k -> top-p -> categorical draw, one workgroup
+// (16 waves) per row of fp32 logits.
+//
+// Semantics follow the reference sampler (orchestration.py:143-169) exactly:
+//   * logits / temperature;
+//   * top-k keeps every logit >= the k-th largest (ties at the k-th value survive);
+//   * top-p sorts the survivors descending, takes softmax + inclusive cumsum and removes entry i
+//     iff cum[i-1] > top_p (the mask is shifted right by one, so the first token that crosses
+//     the threshold is kept and the top-1 is always kept);
+//   * softmax over what is left, then one categorical sample.
+// Differences by design: temperature <= 0 means greedy argmax (the reference divides by zero),
+// and the draw uses a counter-based Philox4x32-10 keyed by (seed, step) per row, so a request is
+// reproducible regardless of batching (the reference uses the global unseeded torch RNG).
+//
+// Method: exact radix select (4 x 8 bit) of the k-th largest key, gather of the >= k-th
+// candidates into LDS (at most kCap), bitonic sort of the candidates, block scan for the
+// cumulative mass. Since top-k runs first, top-p only ever touches the <= kCap survivors.
+#include "common.h"
+#include "launch.h"
+
+namespace dlia {
+
+constexpr int kSampThreads = 1024;
+constexpr int kCap = 1024;            // max candidates kept after top-k (k is clamped to this)
+
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __builtin_bit_cast(unsigned, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // monotone: larger float -> larger key
+}
+
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], const unsigned (&k)[2]) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+  const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k[0];
+  const unsigned n1 = (unsigned)p1;
+  const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k[1];
+  const unsigned n3 = (unsigned)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned step, unsigned row) {
+  unsigned c[4] = {step, row, 0u, 0u};
+  unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k);
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+  }
+  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);       // [0, 1)
+}
+
+struct SampleParams {
+  int* out; const float* logits; long ldl;
+  const float* temperature; const int* top_k; const float* top_p;
+  const unsigned long long* seeds; const int* steps;
+  int vocab;
+  float* dbg_probs; int* dbg_ids; int dbg_cap;
+};
+
+__global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_krem, s_ncand;
+  __shared__ float cval[kCap];
+  __shared__ int cidx[kCap];
+  __shared__ float wsum[16];
+  __shared__ float s_red[16];
+  __shared__ int s_redi[16];
+
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = p.logits + (long)r * p.ldl;
+  const int V = p.vocab;
+  const float temp = p.temperature ? p.temperature[r] : 1.f;
+
+  if (temp <= 0.f) {
+    // greedy: max value, lowest index among ties
+    float bv = -__builtin_inff(); int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += kSampThreads) {
+      const float v = row[i];
+      if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_red[wave] = bv; s_redi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 16; ++w)
+        if (s_red[w] > bv || (s_red[w] == bv && s_redi[w] < bi)) { bv = s_red[w]; bi = s_redi[w]; }
+      p.out[r] = bi == 0x7fffffff ? 0 : bi;
+      if (p.dbg_probs) {
+        for (int i = 0; i < p.dbg_cap; ++i) { p.dbg_probs[(long)r * p.dbg_cap + i] = i == 0 ? 1.f : 0.f;
+                                              p.dbg_ids[(long)r * p.dbg_cap + i] = i == 0 ? bi : -1; }
+      }
+    }
+    return;
+  }
+
+  int k = p.top_k ? p.top_k[r] : 0;
+  if (k <= 0 || k > kCap) k = kCap;
+  if (k > V) k = V;
+  const float top_p = p.top_p ? p.top_p[r] : 1.f;
+
+  // ---- exact radix select of the k-th largest key -------------------------------------
+  if (tid == 0) { s_prefix = 0u; s_krem = (unsigned)k; s_ncand = 0u; }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = tid; i < V; i += kSampThreads) {
+      const unsigned key = f2key(row[i]);
+      if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane owns bins 4*lane .. 4*lane+3; suffix-scan lane sums from the top
+      const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned suf = mine;                       // inclusive suffix sum over lanes >= lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+      }
+      const unsigned krem = s_krem;
+      const unsigned above = suf - mine;         // count in bins above this lane's bins
+      const bool hit = above < krem && krem <= suf;
+      if (hit) {
+        unsigned cnt = above; int bin;
+        if (cnt + h3 >= krem) bin = 3;
+        else { cnt += h3; if (cnt + h2 >= krem) bin = 2;
+          else { cnt += h2; if (cnt + h1 >= krem) bin = 1; else { cnt += h1; bin = 0; } } }
+        s_prefix = prefix | ((unsigned)(4 * lane + bin) << shift);
+        s_krem = krem - cnt;
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned kth = s_prefix;
+
+  // ---- gather candidates (key >= kth) ---------------------------------------------------
+  for (int i = tid; i < V; i += kSampThreads) {
+    const float v = row[i];
+    if (f2key(v) >= kth) {
+      const unsigned slot = atomicAdd(&s_ncand, 1u);
+      if (slot < (unsigned)kCap) { cval[slot] = v; cidx[slot] = i; }
+    }
+  }
+  __syncthreads();
+  const int ncand = min((int)s_ncand, kCap);
+  if (tid >= ncand) { cval[tid] = -__builtin_inff(); cidx[tid] = 0x7fffffff; }
+  __syncthreads();
+
+  // ---- bitonic sort, descending by value, ascending index among equals -----------------
+  for (int size = 2; size <= kCap; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = tid ^ stride;
+      if (partner > tid) {
+        const float a = cval[tid], b = cval[partner];
+        const int ai = cidx[tid], bi = cidx[partner];
+        const bool a_first = a > b || (a == b && ai < bi);     // a should precede b in final order
+        const bool up = (tid & size) == 0;                     // this pair sorts "descending"
+        if (up ? !a_first : a_first) { cval[tid] = b; cval[partner] = a; cidx[tid] = bi; cidx[partner] = ai; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- softmax numerators, inclusive scan ----------------------------------------------
+  const float inv_t = 1.f / temp;
+  const float zmax = cval[0];
+  const float e = tid < ncand ? __expf((cval[tid] - zmax) * inv_t) : 0.f;
+  float sc = e;                                              // inclusive scan within the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(sc, o, 64);
+    if (lane >= o) sc += t;
+  }
+  if (lane == 63) wsum[wave] = sc;
+  __syncthreads();
+  float woff = 0.f, total = 0.f;
+  for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+  const float cum = sc + woff;                               // inclusive cumulative mass
+  const float prev = cum - e;                                // cum[i-1]
+  const bool keep = tid < ncand && (tid == 0 || top_p >= 1.f || !(prev / total > top_p));
+  // kept entries form a prefix; its size and mass:
+  const unsigned long long bal = __ballot(keep);
+  if (lane == 0) s_redi[wave] = __popcll(bal);
+  __syncthreads();
+  int nkeep = 0;
+  for (int w = 0; w < 16; ++w) nkeep += s_redi[w];
+  __syncthreads();
+  if (tid == nkeep - 1) s_red[0] = cum;
+  __syncthreads();
+  const float kept_total = s_red[0];
+
+  // ---- categorical draw -------------------------------------------------------------------
+  const float u = philox_uniform(p.seeds ? p.seeds[r] : 0ull, p.steps ? (unsigned)p.steps[r] : 0u, (unsigned)r);
+  const float target = u * kept_total;
+  const bool below = tid < nkeep && cum <= target;           // entries entirely below the target
+  const unsigned long long bb = __ballot(below);
+  __syncthreads();
+  if (lane == 0) s_redi[wave] = __popcll(bb);
+  __syncthreads();
+  if (tid == 0) {
+    int pick = 0;
+    for (int w = 0; w < 16; ++w) pick += s_redi[w];
+    if (pick >= nkeep) pick = nkeep - 1;
+    p.out[r] = cidx[pick];
+  }
+  if (p.dbg_probs && tid < p.dbg_cap) {
+    p.dbg_probs[(long)r * p.dbg_cap + tid] = tid < nkeep ? e / kept_total : 0.f;
+    p.dbg_ids[(long)r * p.dbg_cap + tid] = tid < nkeep ? cidx[tid] : -1;
+  }
+}
+
+}  // namespace dlia
+
+extern "C" void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
+                            const int* top_k, const float* top_p, const uint64_t* seeds,
+                            const int* steps, int R, int vocab, long ldl, float* dbg_probs,
+                            int* dbg_ids, int dbg_cap, hipStream_t stream) {
+  if (R <= 0) return;
+  dlia::SampleParams p;
+  p.out = out_tokens; p.logits = logits; p.ldl = ldl; p.temperature = temperature; p.top_k = top_k;
+  p.top_p = top_p; p.seeds = (const unsigned long long*)seeds; p.steps = steps; p.vocab = vocab;
+  p.dbg_probs = dbg_probs; p.dbg_ids = dbg_ids; p.dbg_cap = dbg_cap > dlia::kCap ? dlia::kCap : dbg_cap;
+  hipLaunchKernelGGL(dlia::sample_kernel, dim3(R), dim3(dlia::kSampThreads), 0, stream, p);
+}
