@@ -1,0 +1,376 @@
+"""MI355X pipeline-stage executor: a contiguous range of decoder layers (plus embedding on the
+first stage and final norm + lm_head + sampler on the last) running entirely on this engine's
+HIP kernels, with a paged KV cache for the stage's own layers.
+
+Hot path per decoder layer (Llama):
+    norm -> qkv GEMM -> rope + paged-KV write -> paged attention -> o GEMM (+residual)
+         -> norm -> gate/up GEMM (silu*mul epilogue) -> down GEMM (+residual)
+GEMMs switch between the weight-streaming kernel (<= 64 rows: decode) and the tiled MFMA
+kernel (prefill) on the row count. Decode steps of a micro-batch are captured once into a
+hipGraph (torch.cuda.CUDAGraph) over static buffers and replayed; the per-step device state
+(context lengths, RNG counters) is advanced inside the graph, so a steady-state decode step
+needs no host->device traffic at all.
+
+Same interface as `RefStage`; what it replaces in the reference is `Worker.process`
+(Worker1.py:82-177) and the orchestrator's embed / norm / lm_head / sampling
+(orchestration.py:111,140-169).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import ops
+from ..ops import packing
+from ..runtime.batch import StepBatch
+from .partition import StagePlan
+from .rope import build_rope_table
+from .spec import ModelSpec
+from .weights import StageWeights
+
+BLOCK = packing.KV_BLOCK
+
+
+@dataclass
+class _MicroBatchState:
+    """Static device buffers (and the captured graph) of one in-flight decode micro-batch."""
+    B: int
+    slots: torch.Tensor          # int32 [B]   KV slot of each row (= tok_seq for decode)
+    ctx: torch.Tensor            # int32 [B]   cached tokens (= tok_pos for decode); advanced in-graph
+    ids: torch.Tensor            # int32 [B]   stage-0 input tokens
+    hidden_in: Optional[torch.Tensor]    # bf16 [B, H] (stages > 0)
+    hidden_out: Optional[torch.Tensor]   # bf16 [B, H] (stages < last)
+    tokens: Optional[torch.Tensor]       # int32 [B]  (last stage)
+    temperature: torch.Tensor
+    top_k: torch.Tensor
+    top_p: torch.Tensor
+    seeds: torch.Tensor
+    steps: torch.Tensor          # int32 [B] RNG counters; advanced in-graph
+    graph: Optional[torch.cuda.CUDAGraph] = None
+    splits: int = 1
+
+
+class GpuStage:
+    backend = "hip"
+
+    def __init__(self, spec: ModelSpec, plan: StagePlan, weights: StageWeights, *, device="cuda",
+                 max_slots: int = 256, max_seq_len: int = 2048, num_blocks: Optional[int] = None,
+                 max_tokens: int = 2048, max_batch: int = 64, use_graphs: bool = True,
+                 kv_mem_fraction: float = 0.85):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
+        if spec.head_dim not in (64, 128):
+            raise ValueError("the HIP attention kernels support head_dim 64 and 128")
+        self.K = ops.load()
+        self.spec, self.plan = spec, plan
+        self.device = torch.device(device)
+        self.max_slots, self.max_seq_len = max_slots, max_seq_len
+        self.max_blocks = (max_seq_len + BLOCK - 1) // BLOCK
+        self.max_tokens = max(max_tokens, max_batch)
+        self.max_batch = max_batch
+        self.use_graphs = use_graphs
+        self.null_slot = max_slots            # extra block-table row that never owns blocks
+        dev, bf = self.device, torch.bfloat16
+        H, I, V = spec.hidden_size, spec.intermediate_size, spec.vocab_size
+
+        # ---- weights: move, cast, pack into MFMA-fragment order ---------------------------
+        g = lambda t: None if t is None else t.to(device=dev, dtype=bf).contiguous()
+        self.embed = g(weights.embed) if plan.has_embed else None
+        self.pos_embed = g(weights.pos_embed) if plan.has_embed else None
+        self.layers: List[Dict[str, torch.Tensor]] = []
+        for i in range(len(weights.layers)):
+            l = weights.layers[i]
+            p: Dict[str, torch.Tensor] = {"ln1_w": g(l["ln1_w"]), "ln2_w": g(l["ln2_w"])}
+            p["w_qkv"] = packing.pack_weight(g(l["w_qkv"]))
+            p["w_o"] = packing.pack_weight(g(l["w_o"]))
+            p["w_down"] = packing.pack_weight(g(l["w_down"]))
+            if spec.is_llama:
+                p["w_gu"] = packing.pack_weight(packing.interleave_gate_up(g(l["w_gate"]), g(l["w_up"])))
+            else:
+                p["w_fc"] = packing.pack_weight(g(l["w_fc"]))
+                for k in ("ln1_b", "ln2_b", "b_qkv", "b_o", "b_fc", "b_down"):
+                    p[k] = g(l[k])
+            self.layers.append(p)
+            weights.layers[i] = {}                 # drop the logical copy as we go (peak memory)
+        self.vocab_pad = packing.padded_n(V)
+        if plan.has_head:
+            self.final_norm_w = g(weights.final_norm_w)
+            self.final_norm_b = g(weights.final_norm_b)
+            self.lm_head = packing.pack_weight(g(weights.lm_head))
+        if spec.is_llama:
+            self.cos, self.sin = build_rope_table(spec, max_seq_len, dev)
+        else:
+            self.cos = self.sin = torch.zeros(1, spec.head_dim // 2, device=dev)
+
+        # ---- paged KV cache for this stage's layers ---------------------------------------
+        L = plan.num_layers
+        blk_bytes = L * spec.num_kv_heads * 2 * BLOCK * spec.head_dim * 2
+        if num_blocks is None:
+            free, _ = torch.cuda.mem_get_info(dev)
+            budget = int(free * kv_mem_fraction) - self._workspace_bytes()
+            num_blocks = max(self.max_blocks, min(budget // max(blk_bytes, 1), max_slots * self.max_blocks))
+        self.num_blocks = int(num_blocks)
+        # zero-filled: masked-out (never written) slots must hold finite values, P=0 times NaN is NaN
+        self.kv = torch.zeros(max(L, 1), self.num_blocks, spec.num_kv_heads, 2, BLOCK * spec.head_dim,
+                              device=dev, dtype=bf)
+        self.block_table = torch.full((max_slots + 1, self.max_blocks), -1, device=dev, dtype=torch.int32)
+
+        # ---- activation workspaces ----------------------------------------------------------
+        MT = self.max_tokens
+        z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
+        self.h = z(MT, H)
+        self.xn = z(MT, H)
+        self.qkv = z(MT, spec.qkv_size)
+        self.attn = z(MT, spec.q_size)
+        self.act = z(MT, I)
+        self.ws = z(16 * 64 * max(spec.qkv_size, 2 * I if spec.is_llama else I, H), dt=torch.float32)
+        self.max_splits = 16
+        self.attn_ws = z(int(self.K.attention_ws_floats(max_batch, 1, spec.num_heads, spec.num_kv_heads,
+                                                        spec.head_dim, self.max_splits)), dt=torch.float32)
+        if plan.has_head:
+            self.head_x = z(max_batch, H)
+            self.logits = z(max_batch, self.vocab_pad, dt=torch.float32)
+        # eager-path metadata (device) + pinned staging
+        i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
+        self.md_tok_pos, self.md_tok_seq = i32(MT), i32(MT)
+        self.md_q_start, self.md_ctx, self.md_slots = i32(max_batch + 1), i32(max_batch), i32(max_batch)
+        self.md_rows, self.md_ids = i32(max_batch), i32(MT)
+        self._mbs: Dict[int, _MicroBatchState] = {}
+        self.scale = 1.0 / math.sqrt(spec.head_dim)
+        self.graph_replays = 0
+
+    def _workspace_bytes(self) -> int:
+        s = self.spec
+        per_tok = 2 * (2 * s.hidden_size + s.qkv_size + s.q_size + s.intermediate_size)
+        return self.max_tokens * per_tok + (1 << 30)
+
+    # ---- block tables ---------------------------------------------------------------------
+    def set_tables(self, batch: StepBatch):
+        for slot, blocks in zip(batch.table_slots, batch.table_blocks):
+            if not (0 <= slot < self.max_slots):
+                raise ValueError(f"slot {slot} out of range")
+            if len(blocks) > self.max_blocks or any(b < 0 or b >= self.num_blocks for b in blocks):
+                raise ValueError(f"bad block table for slot {slot}")
+            row = torch.full((self.max_blocks,), -1, dtype=torch.int32)
+            row[:len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
+            self.block_table[slot].copy_(row.to(self.device, non_blocking=False))
+
+    def release(self, slots: List[int]):
+        for s in slots:
+            if 0 <= s < self.max_slots:
+                self.block_table[s].fill_(-1)
+
+    # ---- the layer stack on T tokens ------------------------------------------------------
+    def _layers(self, T: int, B: int, tok_pos, tok_seq, q_start, ctx, slots, max_q: int, splits: int):
+        K, s = self.K, self.spec
+        h, xn, qkv, attn, act = self.h[:T], self.xn[:T], self.qkv[:T], self.attn[:T], self.act[:T]
+        Hq, Hkv, D, H, I = s.num_heads, s.num_kv_heads, s.head_dim, s.hidden_size, s.intermediate_size
+        ws = self.ws if T <= 64 else None
+        partial = self.attn_ws if splits > 1 else None
+        llama = s.is_llama
+        for li, p in enumerate(self.layers):
+            kv = self.kv[li]
+            K.norm(xn, h, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, not llama)
+            K.gemm(qkv, xn, p["w_qkv"], p.get("b_qkv"), None, ws, s.qkv_size, 0 if llama else 1, 0)
+            K.rope_kvwrite(qkv, kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table, Hq, Hkv, D, llama)
+            K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
+                              self.scale, splits)
+            K.gemm(h, attn, p["w_o"], p.get("b_o"), h, ws, H, 2 if llama else 3, 0)
+            K.norm(xn, h, None, p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, not llama)
+            if llama:
+                K.gemm(act, xn, p["w_gu"], None, None, ws, 2 * I, 4, 0)
+                K.gemm(h, act, p["w_down"], None, h, ws, H, 2, 0)
+            else:
+                K.gemm(act, xn, p["w_fc"], p["b_fc"], None, ws, I, 5, 0)
+                K.gemm(h, act, p["w_down"], p["b_down"], h, ws, H, 3, 0)
+
+    def _head(self, rows_idx: torch.Tensor, R: int):
+        """Final norm on the selected rows of self.h, then lm_head -> self.logits[:R]."""
+        s, K = self.spec, self.K
+        hx = self.head_x[:R]
+        K.norm(hx, self.h, None, self.final_norm_w, self.final_norm_b, rows_idx[:R], s.norm_eps, not s.is_llama)
+        K.gemm(self.logits[:R], hx, self.lm_head, None, None, self.ws, self.vocab_pad, 0, 0)
+        return self.logits[:R]
+
+    # ---- generic (eager) forward: prefill chunks, and decode when graphs are off ---------
+    @torch.no_grad()
+    def forward(self, batch: StepBatch, x: Optional[torch.Tensor]) -> torch.Tensor:
+        s = self.spec
+        B, T = batch.num_seqs, batch.num_tokens
+        if B > self.max_batch or T > self.max_tokens:
+            raise ValueError(f"step with {B} sequences / {T} tokens exceeds the stage limits "
+                             f"({self.max_batch} / {self.max_tokens})")
+        self.set_tables(batch)
+        tok_pos, tok_seq, q_start, rows = [], [], [0], []
+        for slot, q, c, smp in zip(batch.slots, batch.q_lens, batch.ctx_lens, batch.sample):
+            if c + q > self.max_seq_len:
+                raise ValueError(f"sequence in slot {slot} would reach {c + q} tokens > max_seq_len {self.max_seq_len}")
+            tok_pos += list(range(c, c + q))
+            tok_seq += [slot] * q
+            q_start.append(q_start[-1] + q)
+            if smp and q > 0:
+                rows.append(q_start[-1] - 1)
+        dev = self.device
+        up = lambda dst, vals: dst[:len(vals)].copy_(torch.tensor(vals, dtype=torch.int32), non_blocking=False)
+        up(self.md_tok_pos, tok_pos); up(self.md_tok_seq, tok_seq); up(self.md_q_start, q_start)
+        up(self.md_ctx, batch.ctx_lens); up(self.md_slots, batch.slots)
+        if self.plan.has_embed:
+            ids = x.to(device=dev, dtype=torch.int32).reshape(-1)
+            if ids.numel() != T:
+                raise ValueError(f"expected {T} token ids, got {ids.numel()}")
+            self.K.embed(self.h[:T], ids, self.md_tok_pos[:T], self.embed, self.pos_embed)
+        else:
+            if tuple(x.shape) != (T, s.hidden_size):
+                raise ValueError(f"expected hidden [{T},{s.hidden_size}], got {tuple(x.shape)}")
+            self.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16))
+        max_q = max(batch.q_lens) if batch.q_lens else 1
+        self._layers(T, B, self.md_tok_pos[:T], self.md_tok_seq[:T], self.md_q_start[:B + 1], self.md_ctx[:B],
+                     self.md_slots[:B], max_q, 1)
+        if not self.plan.has_head:
+            return self.h[:T]
+        R = len(rows)
+        if R == 0:
+            return self.logits[:0, :s.vocab_size]
+        up(self.md_rows, rows)
+        return self._head(self.md_rows, R)[:, :s.vocab_size]
+
+    @torch.no_grad()
+    def sample(self, batch: StepBatch, logits: torch.Tensor) -> torch.Tensor:
+        """Tokens (device int32 [num_samples]) for the rows `forward` returned logits for."""
+        idx = [i for i in range(batch.num_seqs) if batch.sample[i] and batch.q_lens[i] > 0]
+        R = len(idx)
+        dev = self.device
+        out = torch.empty(R, device=dev, dtype=torch.int32)
+        if R == 0:
+            return out
+        t = lambda vals, dt: torch.tensor(vals, dtype=dt).to(dev)
+        lg = self.logits[:R]      # `logits` is a view of this buffer (padded columns ignored by `vocab`)
+        self.K.sample(out, lg, t([batch.temperature[i] for i in idx], torch.float32),
+                      t([batch.top_k[i] for i in idx], torch.int32), t([batch.top_p[i] for i in idx], torch.float32),
+                      t([batch.seeds[i] for i in idx], torch.int64), t([batch.sample_steps[i] for i in idx], torch.int32),
+                      self.spec.vocab_size, None, None)
+        return out
+
+    # ---- graph-captured decode ------------------------------------------------------------
+    def _mb_state(self, mb: int, B: int) -> _MicroBatchState:
+        st = self._mbs.get(mb)
+        if st is not None and st.B == B:
+            return st
+        dev, H = self.device, self.spec.hidden_size
+        i32 = lambda: torch.zeros(B, device=dev, dtype=torch.int32)
+        st = _MicroBatchState(
+            B=B, slots=torch.full((B,), self.null_slot, device=dev, dtype=torch.int32), ctx=i32(), ids=i32(),
+            hidden_in=None if self.plan.has_embed else torch.zeros(B, H, device=dev, dtype=torch.bfloat16),
+            hidden_out=None if self.plan.has_head else torch.zeros(B, H, device=dev, dtype=torch.bfloat16),
+            tokens=i32() if self.plan.has_head else None,
+            temperature=torch.zeros(B, device=dev), top_k=i32(), top_p=torch.ones(B, device=dev),
+            seeds=torch.zeros(B, device=dev, dtype=torch.int64), steps=i32())
+        self._mbs[mb] = st
+        return st
+
+    def _decode_body(self, st: _MicroBatchState):
+        """One decode step over the micro-batch's static buffers (captured into the graph)."""
+        K, B = self.K, st.B
+        if self.plan.has_embed:
+            K.embed(self.h[:B], st.ids, st.ctx, self.embed, self.pos_embed)
+        else:
+            self.h[:B].copy_(st.hidden_in)
+        self._layers(B, B, st.ctx, st.slots, self._arange[:B + 1], st.ctx, st.slots, 1, st.splits)
+        if self.plan.has_head:
+            self._head(self._arange, B)
+            K.sample(st.tokens, self.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
+                     self.spec.vocab_size, None, None)
+            K.advance(st.steps, 1)
+        else:
+            st.hidden_out.copy_(self.h[:B])
+        K.advance(st.ctx, 1)
+
+    @torch.no_grad()
+    def decode_step(self, batch: StepBatch, x: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Decode step of micro-batch `batch.micro_batch` over static buffers.
+
+        Returns the static output buffer: hidden [B,H] (not the last stage) or sampled tokens
+        int32 [B] (last stage). When `batch.replay` is set and nothing about the micro-batch
+        changed, this is a bare graph replay. `x` (tokens for stage 0 / hidden otherwise) is
+        copied into the static input when given; a caller that received straight into
+        `input_buffer()` passes None.
+        """
+        B = batch.num_seqs
+        if B > self.max_batch:
+            raise ValueError(f"micro-batch of {B} exceeds max_batch {self.max_batch}")
+        if not hasattr(self, "_arange"):
+            self._arange = torch.arange(self.max_batch + 1, device=self.device, dtype=torch.int32)
+        st = self._mb_state(batch.micro_batch, B)
+        if not batch.replay:
+            self.set_tables(batch)
+            dev = self.device
+            for c in batch.ctx_lens:
+                if c + 1 > self.max_seq_len:
+                    raise ValueError("sequence exceeds max_seq_len")
+            up = lambda dst, vals, dt: dst.copy_(torch.tensor(vals, dtype=dt))
+            # rows whose q_len is 0 are padding: park them on the null slot
+            slots = [s if q == 1 else self.null_slot for s, q in zip(batch.slots, batch.q_lens)]
+            up(st.slots, slots, torch.int32); up(st.ctx, batch.ctx_lens, torch.int32)
+            up(st.temperature, batch.temperature, torch.float32); up(st.top_k, batch.top_k, torch.int32)
+            up(st.top_p, batch.top_p, torch.float32); up(st.seeds, batch.seeds, torch.int64)
+            up(st.steps, batch.sample_steps, torch.int32)
+            if self.plan.has_embed and batch.token_ids is not None:
+                up(st.ids, batch.token_ids, torch.int32)
+            max_ctx = max(batch.ctx_lens) if batch.ctx_lens else 0
+            st.splits_wanted = self._pick_splits(B, max_ctx)
+        if x is not None:
+            (st.ids if self.plan.has_embed else st.hidden_in).copy_(x)
+        if not self.use_graphs:
+            st.splits = getattr(st, "splits_wanted", 1)
+            self._decode_body(st)
+        else:
+            want = getattr(st, "splits_wanted", 1)
+            if st.graph is None or st.splits != want:
+                st.splits = want
+                self._capture(st)
+            st.graph.replay()
+            self.graph_replays += 1
+        return st.tokens if self.plan.has_head else st.hidden_out
+
+    def input_buffer(self, mb: int, B: int) -> torch.Tensor:
+        st = self._mb_state(mb, B)
+        return st.ids if self.plan.has_embed else st.hidden_in
+
+    def _pick_splits(self, B: int, max_ctx: int) -> int:
+        """Split-KV factor: enough waves to fill the chip when sequences x kv-heads is small."""
+        items = B * self.spec.num_kv_heads
+        if max_ctx < 256 or items >= 2048:
+            return 1
+        s = 1
+        while items * s < 2048 and s < self.max_splits and (max_ctx // (s * 2)) >= 64:
+            s *= 2
+        return s
+
+    def _capture(self, st: _MicroBatchState):
+        # Warm up on a side stream (first-use initialisation must not happen under capture), then
+        # capture. The captured step advances ctx/steps, so save and restore them around both.
+        saved = (st.ctx.clone(), st.steps.clone())
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._decode_body(st)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_body(st)
+        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1])
+        st.graph = g
+
+    # ---- introspection ----------------------------------------------------------------------
+    def memory_report(self) -> Dict[str, float]:
+        gib = 1 << 30
+        wbytes = sum(t.numel() * t.element_size() for l in self.layers for t in l.values())
+        for t in (self.embed, self.pos_embed, getattr(self, "lm_head", None)):
+            if t is not None:
+                wbytes += t.numel() * t.element_size()
+        return {"weights_gib": wbytes / gib, "kv_gib": self.kv.numel() * 2 / gib, "kv_blocks": self.num_blocks,
+                "kv_tokens": self.num_blocks * BLOCK}

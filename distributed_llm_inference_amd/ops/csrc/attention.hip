@@ -31,7 +31,9 @@ struct AttnParams {
   const bf16* kv;                 // this layer's cache
   const int* q_start;             // [B+1] first token row of each sequence's chunk
   const int* ctx_lens;            // [B] tokens already cached before this chunk
-  const int* block_table;         // [B, max_blocks]
+  const int* block_table;         // [table_rows, max_blocks]
+  const int* slots;               // optional [B]: block_table row of each sequence (else row b)
+  int table_rows;
   float* partial;                 // split-KV partials
   int B, Hq, Hkv, g_shift;        // group size g = 1 << g_shift
   int max_blocks, num_blocks, qtiles, splits;
@@ -60,6 +62,9 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
   const int t0 = p.q_start[b];
   const int q_len = p.q_start[b + 1] - t0;
   const int ctx = p.ctx_lens[b];
+  int srow = p.slots ? p.slots[b] : b;
+  const bool srow_ok = srow >= 0 && srow < p.table_rows;
+  srow = srow_ok ? srow : 0;
   const int qp0 = qtile * QT;
   const bool tile_live = qp0 < q_len;             // wave-uniform
 
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
 
   const long slab = kv_slab_elems(D);
   for (int kb = kb0; kb < kb1; ++kb) {
-    int blk = p.block_table[(long)b * p.max_blocks + kb];
-    blk = (blk >= 0 && blk < p.num_blocks) ? blk : 0;          // never a wild read
+    int blk = p.block_table[(long)srow * p.max_blocks + kb];
+    blk = (srow_ok && blk >= 0 && blk < p.num_blocks) ? blk : 0;          // never a wild read
     const bf16* kbase = p.kv + kv_head_base(blk, kvh, p.Hkv, D, 0) + lane * 8;
     const bf16* vbase = kbase + slab;
     u32x4 kf[2][KS], vf[DT];
@@ -263,13 +268,13 @@ extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int
 
 extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache,
                                      const int* q_start, const int* ctx_lens, const int* block_table,
-                                     float* partial, int B, int max_q_len, int Hq, int Hkv, int D,
-                                     int max_blocks, int num_blocks, long ldq, long ldo, float scale,
-                                     int splits, hipStream_t stream) {
+                                     const int* slots, float* partial, int B, int max_q_len, int Hq,
+                                     int Hkv, int D, int table_rows, int max_blocks, int num_blocks,
+                                     long ldq, long ldo, float scale, int splits, hipStream_t stream) {
   if (B <= 0 || max_q_len <= 0) return;
   AttnParams p;
   p.out = (bf16*)out; p.ldo = ldo; p.q = (const bf16*)qkv; p.ldq = ldq; p.kv = (const bf16*)kv_cache;
-  p.q_start = q_start; p.ctx_lens = ctx_lens; p.block_table = block_table; p.partial = partial;
+  p.q_start = q_start; p.ctx_lens = ctx_lens; p.block_table = block_table; p.slots = slots; p.table_rows = table_rows; p.partial = partial;
   p.B = B; p.Hq = Hq; p.Hkv = Hkv;
   const int g = Hq / Hkv;
   int gs = 0;

@@ -183,7 +183,7 @@ int64_t attention_ws_floats(int64_t B, int64_t max_q_len, int64_t Hq, int64_t Hk
 }
 
 void paged_attention(Tensor out, const Tensor& qkv, const Tensor& kv_cache, const Tensor& q_start,
-                     const Tensor& ctx_lens, const Tensor& block_table, OptTensor partial,
+                     const Tensor& ctx_lens, const Tensor& block_table, OptTensor slots, OptTensor partial,
                      int64_t max_q_len, int64_t Hq, int64_t Hkv, int64_t D, double scale, int64_t splits) {
   check_bf16(out, "out"); check_bf16(qkv, "qkv"); check_rows(out, "out"); check_rows(qkv, "qkv");
   DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
@@ -194,7 +194,15 @@ void paged_attention(Tensor out, const Tensor& qkv, const Tensor& kv_cache, cons
   auto geo = check_kv(kv_cache, Hkv, D);
   check_i32(q_start, "q_start"); check_i32(ctx_lens, "ctx_lens"); check_i32(block_table, "block_table");
   const int64_t B = ctx_lens.numel();
-  DLIA_CHECK(q_start.numel() == B + 1 && block_table.dim() == 2 && block_table.size(0) >= B, "attention metadata shapes");
+  DLIA_CHECK(q_start.numel() == B + 1 && block_table.dim() == 2, "attention metadata shapes");
+  const int* slp = nullptr;
+  if (slots.has_value()) {
+    check_i32(*slots, "slots");
+    DLIA_CHECK(slots->numel() >= B, "slots shape");
+    slp = slots->data_ptr<int>();
+  } else {
+    DLIA_CHECK(block_table.size(0) >= B, "block_table needs one row per sequence");
+  }
   float* pp = nullptr;
   int sp = (int)splits;
   if (sp > 1) {
@@ -209,8 +217,8 @@ void paged_attention(Tensor out, const Tensor& qkv, const Tensor& kv_cache, cons
   // The caller guarantees: q_start is non-decreasing with q_start[B] <= rows of qkv/out, chunk
   // lengths <= max_q_len, and ctx_lens[b] + q_len[b] <= 32 * block_table.size(1).
   dlia_paged_attention(out.data_ptr(), qkv.data_ptr(), kv_cache.data_ptr(), q_start.data_ptr<int>(),
-                       ctx_lens.data_ptr<int>(), block_table.data_ptr<int>(), pp, (int)B, (int)max_q_len, (int)Hq,
-                       (int)Hkv, (int)D, (int)block_table.size(1), (int)geo.num_blocks, qkv.stride(0),
+                       ctx_lens.data_ptr<int>(), block_table.data_ptr<int>(), slp, pp, (int)B, (int)max_q_len, (int)Hq,
+                       (int)Hkv, (int)D, (int)block_table.size(0), (int)block_table.size(1), (int)geo.num_blocks, qkv.stride(0),
                        out.stride(0), (float)scale, sp, cur_stream());
 }
 
@@ -253,7 +261,7 @@ TORCH_LIBRARY(dlia, m) {
   m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk) -> ()");
   m.def("gemm_splitk(int M, int N, int K) -> int");
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
-  m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
+  m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
   m.def("sample(Tensor(a!) out_tokens, Tensor logits, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
   m.def("advance(Tensor(a!) x, int delta) -> ()");
 }

@@ -48,9 +48,9 @@ void dlia_gemm_tile(void* out, const void* x, const void* wp, const void* bias,
 // kv split); `partial` holds split-KV partials when splits > 1.
 void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache,
                           const int* q_start, const int* ctx_lens, const int* block_table,
-                          float* partial, int B, int max_q_len, int Hq, int Hkv, int D,
-                          int max_blocks, int num_blocks, long ldq, long ldo, float scale,
-                          int splits, hipStream_t stream);
+                          const int* slots, float* partial, int B, int max_q_len, int Hq, int Hkv,
+                          int D, int table_rows, int max_blocks, int num_blocks, long ldq, long ldo,
+                          float scale, int splits, hipStream_t stream);
 long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits);
 
 // ---- sampler.hip ----------------------------------------------------------------------

@@ -1,0 +1,72 @@
+"""Shared test utilities: tiny HF models holding exactly the engine's random weights."""
+import json
+import os
+
+import torch
+
+from distributed_llm_inference_amd.models.partition import make_plans
+from distributed_llm_inference_amd.models.spec import ModelSpec, tiny_spec
+from distributed_llm_inference_amd.models.weights import (export_hf_state_dict, random_stage_weights)
+from distributed_llm_inference_amd.models.safetensors_io import save_safetensors
+from distributed_llm_inference_amd.runtime.batch import StepBatch
+
+
+def full_weights(spec, seed=0, dtype=torch.float32):
+    plan = make_plans(spec, 1)[0]
+    return random_stage_weights(spec, plan, seed=seed, dtype=dtype)
+
+
+def hf_model_from(spec: ModelSpec, seed=0):
+    """A transformers model (fp32, CPU, eval) whose parameters equal `random_stage_weights(seed)`."""
+    import transformers
+    cfg = spec.hf_config()
+    if spec.is_llama:
+        c = transformers.LlamaConfig(**{k: v for k, v in cfg.items() if k not in ("model_type", "architectures")})
+        c._attn_implementation = "eager"
+        model = transformers.LlamaForCausalLM(c)
+    else:
+        c = transformers.GPT2Config(**{k: v for k, v in cfg.items() if k not in ("model_type", "architectures")})
+        c._attn_implementation = "eager"
+        model = transformers.GPT2LMHeadModel(c)
+    sd = export_hf_state_dict([full_weights(spec, seed)])
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    bad = [m for m in missing if "rotary" not in m and "lm_head" not in m and "attn.bias" not in m and "masked_bias" not in m]
+    assert not bad and not unexpected, (bad, unexpected)
+    if spec.tie_embeddings or spec.is_gpt2:
+        model.tie_weights()
+    return model.eval()
+
+
+def write_checkpoint(spec: ModelSpec, path: str, seed=0, shards=1, dtype=torch.float32):
+    """Write an HF-format checkpoint directory (config.json + safetensors[, index])."""
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(spec.hf_config(), f)
+    sd = {k: v.to(dtype) for k, v in export_hf_state_dict([full_weights(spec, seed)]).items()}
+    if shards == 1:
+        save_safetensors(sd, os.path.join(path, "model.safetensors"), {"format": "pt"})
+    else:
+        names = sorted(sd)
+        per = (len(names) + shards - 1) // shards
+        wm = {}
+        for i in range(shards):
+            part = names[i * per:(i + 1) * per]
+            fn = f"model-{i + 1:05d}-of-{shards:05d}.safetensors"
+            save_safetensors({n: sd[n] for n in part}, os.path.join(path, fn), {"format": "pt"})
+            wm.update({n: fn for n in part})
+        with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
+            json.dump({"metadata": {}, "weight_map": wm}, f)
+    return path
+
+
+def step(slots, q_lens, ctx_lens, token_ids=None, sample=None, temperature=0.0, mb=0, step_id=0,
+         tables=None, top_k=50, top_p=0.9, seeds=None, sample_steps=None):
+    B = len(slots)
+    return StepBatch(step_id=step_id, micro_batch=mb, slots=list(slots), q_lens=list(q_lens), ctx_lens=list(ctx_lens),
+                     sample=list(sample) if sample is not None else [1] * B,
+                     temperature=[temperature] * B, top_k=[top_k] * B, top_p=[top_p] * B,
+                     seeds=list(seeds) if seeds is not None else [0] * B,
+                     sample_steps=list(sample_steps) if sample_steps is not None else [0] * B,
+                     table_slots=list(tables.keys()) if tables else [],
+                     table_blocks=[list(v) for v in tables.values()] if tables else [],
+                     token_ids=list(token_ids) if token_ids is not None else None)

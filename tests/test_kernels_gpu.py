@@ -193,7 +193,7 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True):
         n = K.attention_ws_floats(B, max_q, Hq, Hkv, D, splits)
         partial = torch.full((n,), float("nan"), device=DEV, dtype=torch.float32)
     scale = 1.0 / math.sqrt(D)
-    K.paged_attention(out, qkv, kv, q_start_t, ctx_t, block_table, partial, max_q, Hq, Hkv, D, scale, splits)
+    K.paged_attention(out, qkv, kv, q_start_t, ctx_t, block_table, None, partial, max_q, Hq, Hkv, D, scale, splits)
     torch.cuda.synchronize()
 
     # reference

@@ -1,0 +1,66 @@
+"""The torch stage executor against Hugging Face transformers (CPU fp32) on tiny random
+checkpoints: full-model logits for prefill and for N cached decode steps. The KV-cache path must
+equal full recompute, i.e. what the reference computes by resending the whole sequence
+(orchestration.py:109-141)."""
+import pytest
+import torch
+
+from distributed_llm_inference_amd.models.partition import make_plans
+from distributed_llm_inference_amd.models.spec import tiny_spec
+from distributed_llm_inference_amd.models.stage_ref import RefStage
+from distributed_llm_inference_amd.models.weights import random_stage_weights
+
+from helpers import hf_model_from, step
+
+
+@pytest.mark.parametrize("family", ["llama", "gpt2"])
+def test_ref_matches_transformers(family):
+    spec = tiny_spec(family)
+    hf = hf_model_from(spec, seed=3)
+    plan = make_plans(spec, 1)[0]
+    st = RefStage(spec, plan, random_stage_weights(spec, plan, seed=3))
+    torch.manual_seed(0)
+    ids = torch.randint(3, spec.vocab_size, (1, 19))
+    with torch.no_grad():
+        want = hf(ids).logits[0]                        # [S, V] full recompute
+    # prefill 12 tokens in two chunks (7 + 5), then 7 single-token decode steps
+    got = []
+    lg = st.forward(step([0], [7], [0], sample=[1]), ids[0, :7])
+    got.append((6, lg[0]))
+    lg = st.forward(step([0], [5], [7]), ids[0, 7:12])
+    got.append((11, lg[0]))
+    for p in range(12, 19):
+        lg = st.forward(step([0], [1], [p]), ids[0, p:p + 1])
+        got.append((p, lg[0]))
+    for pos, row in got:
+        assert torch.allclose(row, want[pos], atol=2e-4, rtol=1e-4), f"{family} logits differ at position {pos}"
+
+
+def test_ref_llama3_rope_scaling_matches_transformers():
+    from distributed_llm_inference_amd.models.spec import RopeScaling
+    spec = tiny_spec("llama", rope_theta=500000.0,
+                     rope_scaling=RopeScaling(8.0, 1.0, 4.0, 64), max_position=512)
+    hf = hf_model_from(spec, seed=1)
+    plan = make_plans(spec, 1)[0]
+    st = RefStage(spec, plan, random_stage_weights(spec, plan, seed=1))
+    ids = torch.randint(3, spec.vocab_size, (1, 200))
+    with torch.no_grad():
+        want = hf(ids).logits[0, -1]
+    got = st.forward(step([5], [200], [0]), ids[0])[0]
+    assert torch.allclose(got, want, atol=3e-4, rtol=1e-4)
+
+
+def test_ref_ragged_batch_equals_single():
+    spec = tiny_spec("llama")
+    plan = make_plans(spec, 1)[0]
+    w = random_stage_weights(spec, plan, seed=0)
+    a, b = RefStage(spec, plan, w), RefStage(spec, plan, w)
+    x0 = torch.randint(3, spec.vocab_size, (9,))
+    x1 = torch.randint(3, spec.vocab_size, (4,))
+    la = a.forward(step([0, 1], [9, 4], [0, 0]), torch.cat([x0, x1]))
+    l0 = b.forward(step([0], [9], [0]), x0)
+    l1 = b.forward(step([1], [4], [0]), x1)
+    assert torch.allclose(la[0], l0[0], atol=1e-5) and torch.allclose(la[1], l1[0], atol=1e-5)
+    # sample flags select rows
+    lc = a.forward(step([0, 1], [1, 1], [9, 4], sample=[0, 1]), torch.tensor([5, 6]))
+    assert lc.shape[0] == 1
