@@ -1,0 +1,137 @@
+"""Typed engine configuration (dataclass <- YAML / CLI / environment).
+
+The reference has no config system: model name, worker URLs, layer ranges, ports and the ngrok
+token are module constants edited by hand before running (orchestration.py:20-24;
+Worker1.py:26-31), `top_k`/`top_p` are literals in the route (orchestration.py:353-354), the
+generation cap is a literal 30 (orchestration.py:347) and the number of workers (2) is baked
+into the control flow. Everything is a field here, and the pipeline is N-stage generic.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+
+@dataclass
+class EngineConfig:
+    # ---- model -------------------------------------------------------------------------
+    model: str = "tinyllama-1.1b"          # built-in name or HF checkpoint directory
+    weights: str = "auto"                  # "auto": checkpoint if `model` is a dir with weights, else random
+    dtype: str = "bf16"                    # GPU compute dtype: bf16 (fp8 weights: "fp8")
+    seed: int = 0                          # random-init seed
+    tokenizer: Optional[str] = None        # tokenizer directory (default: the model directory; else byte fallback)
+    # ---- pipeline ----------------------------------------------------------------------
+    pp_size: int = 1                       # number of pipeline stages (= processes = GPUs)
+    partition: str = "balanced"            # "balanced" | "even" | "explicit"
+    layer_ranges: Optional[List[Tuple[int, int]]] = None
+    backend: str = "auto"                  # stage executor: "hip" | "torch" | "auto"
+    device: str = "auto"                   # "cuda" | "cpu" | "auto"
+    transport: str = "auto"                # "rccl" | "gloo" | "loopback" | "http" | "auto"
+    # ---- batching / memory ------------------------------------------------------------
+    max_batch: int = 64                    # sequences per micro-batch
+    num_micro_batches: int = 0             # in-flight micro-batches (0 -> pp_size, >= 1)
+    max_seq_len: int = 2048
+    prefill_chunk: int = 2048              # max new tokens per prefill step
+    kv_blocks: int = 0                     # KV blocks per stage (0 -> from memory fraction / max_seq_len)
+    kv_mem_fraction: float = 0.85
+    use_graphs: bool = True                # hipGraph-captured decode
+    max_inflight_steps: int = 2            # steps of one micro-batch issued ahead of their results
+    # ---- sampling defaults (reference values) -----------------------------------------
+    temperature: float = 0.7               # orchestration.py:341
+    top_k: int = 50                        # orchestration.py:353
+    top_p: float = 0.9                     # orchestration.py:354
+    default_max_tokens: int = 20           # orchestration.py:340
+    max_tokens_cap: int = 512              # the reference clamps to 30 (orchestration.py:347)
+    system_prompt: str = "You are a helpful assistant."   # orchestration.py:66
+    chat_template: str = "auto"            # "zephyr" (reference) | "hf" | "none" | "auto"
+    # ---- serving ------------------------------------------------------------------------
+    host: str = "0.0.0.0"                  # orchestration.py:372
+    port: int = 5000                       # orchestration.py:372; workers use 5001.. (Worker1.py:30)
+    worker_urls: List[str] = field(default_factory=list)   # http transport: one URL per worker
+    request_timeout_s: float = 200.0       # Test.py:71
+    hop_timeout_s: float = 30.0            # orchestration.py:118
+    health_timeout_s: float = 5.0          # orchestration.py:313
+    debug_top5: bool = False               # orchestration.py:172-178
+    trace_path: Optional[str] = None       # write a Chrome trace of step timelines here
+    # ---- fault injection (tests) ------------------------------------------------------
+    fault_inject: str = ""                 # e.g. "stage1:exit@3", "stage1:stall@2:5.0", "stage0:raise@1"
+
+    def __post_init__(self):
+        if self.pp_size < 1:
+            raise ValueError("pp_size must be >= 1")
+        if self.num_micro_batches <= 0:
+            self.num_micro_batches = max(1, self.pp_size)
+        if self.layer_ranges is not None:
+            self.layer_ranges = [tuple(r) for r in self.layer_ranges]
+            self.partition = "explicit"
+        if self.dtype not in ("bf16", "fp32", "fp8"):
+            raise ValueError(f"unsupported dtype {self.dtype!r}")
+        if self.max_batch < 1 or self.max_seq_len < 8:
+            raise ValueError("max_batch / max_seq_len out of range")
+
+    # ---- construction helpers ---------------------------------------------------------
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any]) -> "EngineConfig":
+        names = {f.name for f in dataclasses.fields(cls)}
+        unknown = set(d) - names
+        if unknown:
+            raise ValueError(f"unknown config keys: {sorted(unknown)}")
+        return cls(**d)
+
+    @classmethod
+    def from_yaml(cls, path: str, **overrides) -> "EngineConfig":
+        import yaml
+        with open(path) as f:
+            d = yaml.safe_load(f) or {}
+        d.update({k: v for k, v in overrides.items() if v is not None})
+        return cls.from_dict(d)
+
+    @classmethod
+    def from_env(cls, base: Optional["EngineConfig"] = None, prefix: str = "DLIA_") -> "EngineConfig":
+        """Environment overrides: DLIA_PP_SIZE=4, DLIA_MODEL=llama-3-8b, ..."""
+        d = dataclasses.asdict(base) if base else {}
+        for f in dataclasses.fields(cls):
+            v = os.environ.get(prefix + f.name.upper())
+            if v is None:
+                continue
+            d[f.name] = _coerce(v, f.type)
+        return cls.from_dict(d)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return dataclasses.asdict(self)
+
+    def resolved_device(self) -> str:
+        if self.device != "auto":
+            return self.device
+        import torch
+        return "cuda" if torch.cuda.is_available() else "cpu"
+
+    def resolved_backend(self) -> str:
+        if self.backend != "auto":
+            return self.backend
+        return "hip" if self.resolved_device() == "cuda" else "torch"
+
+    def resolved_transport(self) -> str:
+        if self.transport != "auto":
+            return self.transport
+        if self.pp_size == 1:
+            return "loopback"
+        return "rccl" if self.resolved_device() == "cuda" else "gloo"
+
+
+def _coerce(v: str, typ) -> Any:
+    t = str(typ)
+    if "bool" in t:
+        return v.lower() in ("1", "true", "yes", "on")
+    if "int" in t and "List" not in t and "Tuple" not in t:
+        return int(v)
+    if "float" in t:
+        return float(v)
+    if "List[str]" in t:
+        return [s for s in v.split(",") if s]
+    if "Tuple" in t:
+        # "0-11,11-22"
+        return [tuple(int(x) for x in part.split("-")) for part in v.split(",") if part]
+    return v

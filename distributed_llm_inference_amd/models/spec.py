@@ -252,6 +252,15 @@ BUILTIN_SPECS["llama3-70b"] = BUILTIN_SPECS["llama-3-70b"]
 BUILTIN_SPECS["meta-llama-3-70b"] = BUILTIN_SPECS["llama-3-70b"]
 
 
+def _register_test_models():
+    # resolvable by name in spawned stage processes too (tests of the multi-process pipeline)
+    BUILTIN_SPECS["tiny-llama-test"] = tiny_spec("llama")
+    BUILTIN_SPECS["tiny-gpt2-test"] = tiny_spec("gpt2")
+    BUILTIN_SPECS["tiny-llama-gpu-test"] = tiny_spec(
+        "llama", name="tiny-llama-gpu-test", hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
+        intermediate_size=512, vocab_size=320, num_layers=4)
+
+
 def tiny_spec(family: str = "llama", **overrides) -> ModelSpec:
     """A toy architecture for unit tests (seconds on CPU)."""
     if family == "llama":
@@ -264,3 +273,6 @@ def tiny_spec(family: str = "llama", **overrides) -> ModelSpec:
                     norm_eps=1e-5, tie_embeddings=True, bos_token_id=0, eos_token_id=0)
     base.update(overrides)
     return ModelSpec(**base)
+
+
+_register_test_models()

@@ -284,6 +284,8 @@ class GpuStage:
             K.sample(st.tokens, self.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
                      self.spec.vocab_size, None, None)
             K.advance(st.steps, 1)
+            if self.plan.has_embed:
+                st.ids.copy_(st.tokens)      # single-stage pipeline: the feedback hop is local
         else:
             st.hidden_out.copy_(self.h[:B])
         K.advance(st.ctx, 1)

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
 
   // kv block range of this split
   const int tile_q_end = min(q_len, qp0 + QT);
-  const int kv_len = tile_live ? ctx + tile_q_end : 0;
+  // a row that ran past its table (a finished sequence still riding in a fixed-shape batch)
+  // is clamped to the table: reads stay in bounds, its output is discarded by the scheduler
+  const int kv_len = tile_live ? min(ctx + tile_q_end, p.max_blocks * kBlockTokens) : 0;
   const int nb = (kv_len + kBlockTokens - 1) / kBlockTokens;
   const int per = (nb + p.splits - 1) / p.splits;
   const int kb0 = split * per, kb1 = min(nb, kb0 + per);

@@ -1,0 +1,226 @@
+"""Per-stage pipeline runtime.
+
+`StageRuntime.execute(desc)` is what one stage does for one step descriptor:
+
+    stage 0      : tokens (explicit, or the ids the last stage fed back for this micro-batch)
+                   -> embed -> layers -> forward descriptor, send hidden to stage 1
+    stage i      : recv hidden -> layers -> forward descriptor, send hidden
+    last stage   : recv hidden -> layers -> final norm + lm_head on the sampled rows -> sampler
+                   -> send int32 token ids back to stage 0
+    (one stage   : all of the above locally)
+
+Decode steps run over the micro-batch's static buffers (hipGraph replay on the GPU backend):
+receives land directly in the graph's input buffer and sends leave from its output buffer.
+All GPU work and RCCL transfers are enqueued asynchronously; the host only ever blocks on the
+control ring waiting for the next descriptor.
+
+`stage_main` is the loop every non-zero rank runs; rank 0 drives its own StageRuntime from the
+engine's scheduler. This replaces the reference's Flask `/process` worker (Worker1.py:208-245)
+and the orchestrator's relay loop (orchestration.py:109-137) with a true stage->stage chain.
+"""
+from __future__ import annotations
+
+import os
+import time
+import traceback
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from ..runtime.batch import KIND_PING, KIND_RELEASE, KIND_SHUTDOWN, KIND_STEP, StepBatch
+from .transport import Handle, PipelineLinks
+
+
+class FaultInjector:
+    """Test hook: "stage1:exit@3" (die at step 3), "stage1:stall@2:5.0" (sleep 5 s at step 2),
+    "stage0:raise@1" (raise inside execute). Several rules separated by commas."""
+
+    def __init__(self, spec: str, stage: int):
+        self.rules = []
+        for part in (spec or "").split(","):
+            part = part.strip()
+            if not part:
+                continue
+            who, what = part.split(":", 1)
+            if who != f"stage{stage}":
+                continue
+            action, rest = what.split("@", 1)
+            bits = rest.split(":")
+            self.rules.append((action, int(bits[0]), float(bits[1]) if len(bits) > 1 else 0.0))
+        self.count = 0
+
+    def tick(self):
+        self.count += 1
+        for action, at, arg in self.rules:
+            if self.count != at:
+                continue
+            if action == "exit":
+                os._exit(17)
+            if action == "stall":
+                time.sleep(arg)
+            if action == "raise":
+                raise RuntimeError(f"injected fault at step {at}")
+
+
+class StageRuntime:
+    def __init__(self, executor, links: PipelineLinks, board=None, fault: str = "", tracer=None):
+        self.ex = executor
+        self.links = links
+        self.board = board
+        self.stage = links.stage
+        self.fault = FaultInjector(fault, links.stage)
+        self.tracer = tracer
+        self.device = getattr(executor, "device", torch.device("cpu"))
+        self.on_gpu = torch.device(self.device).type == "cuda"
+        self.hidden = executor.spec.hidden_size
+        self.act_dtype = torch.bfloat16 if self.on_gpu else getattr(executor, "dtype", torch.float32)
+        self._send_pending: Dict[int, Handle] = {}     # micro-batch -> last send of its output buffer
+        self._fb_bufs: Dict[tuple, torch.Tensor] = {}
+        self._eager_in: Optional[torch.Tensor] = None
+        self._local_fb: Dict[int, torch.Tensor] = {}   # single-stage pipeline: last tokens per micro-batch
+        self.steps = 0
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _graph_decode(self, desc: StepBatch) -> bool:
+        return desc.is_decode and hasattr(self.ex, "decode_step")
+
+    def result_count(self, desc: StepBatch) -> int:
+        """Number of token ids the last stage produces for `desc`: a static-buffer decode step
+        yields one per row (padding rows included), an eager step one per sampled sequence."""
+        return desc.num_seqs if self._graph_decode(desc) else desc.num_samples
+
+    def fb_buffer(self, mb: int, n: int) -> torch.Tensor:
+        """Stage 0: where the fed-back tokens of micro-batch `mb` land."""
+        if hasattr(self.ex, "input_buffer") and self.ex.plan.has_embed:
+            buf = self.ex.input_buffer(mb, n)
+            if buf.numel() == n:
+                return buf
+        key = (mb, n)
+        b = self._fb_bufs.get(key)
+        if b is None:
+            b = torch.zeros(n, dtype=torch.int32, device=self.device)
+            self._fb_bufs[key] = b
+        return b
+
+    # ---- one descriptor ----------------------------------------------------------------------
+    def execute(self, desc: StepBatch, fb_wait: Optional[Handle] = None) -> Optional[torch.Tensor]:
+        """Runs this stage's share of `desc`. Returns sampled tokens (int32 tensor, device) when
+        this is the last stage, else None. `fb_wait`: completion of the feedback receive that
+        filled the stage-0 token buffer for this step."""
+        L = self.links
+        if desc.kind != KIND_STEP:
+            if desc.kind == KIND_RELEASE:
+                self.ex.release(desc.slots)
+            if L.next_ctrl is not None:
+                L.next_ctrl.put(desc.to_bytes())
+            return None
+        t_start = time.perf_counter_ns()
+        self.fault.tick()
+        mb, B, T = desc.micro_batch, desc.num_seqs, desc.num_tokens
+        graph = self._graph_decode(desc)
+
+        # ---- input ----------------------------------------------------------------------
+        x = None
+        if L.is_first:
+            if desc.token_ids is not None:
+                x = torch.tensor(desc.token_ids, dtype=torch.int32)
+                if graph:
+                    x = None          # decode_step uploads explicit ids itself (non-replay path)
+            else:
+                if fb_wait is not None:
+                    fb_wait.wait()
+                if graph:
+                    x = None                       # tokens are already in the graph's static input
+                elif L.num_stages == 1:
+                    x = self._local_fb[mb]
+                else:
+                    x = self.fb_buffer(mb, T)
+        else:
+            if graph:
+                buf = self.ex.input_buffer(mb, B)
+            else:
+                if self._eager_in is None or self._eager_in.shape[0] < T:
+                    self._eager_in = torch.zeros(max(T, 256), self.hidden, dtype=self.act_dtype, device=self.device)
+                buf = self._eager_in[:T]
+            L.prev_data.recv(buf).wait()
+            x = None if graph else buf
+
+        # ---- compute ---------------------------------------------------------------------
+        prev_send = self._send_pending.pop(mb, None)
+        if prev_send is not None:
+            prev_send.wait()          # the output buffer of this micro-batch is free again
+        if graph:
+            out = self.ex.decode_step(desc, x)
+        else:
+            out = self.ex.forward(desc, x)
+            if L.is_last:
+                out = self.ex.sample(desc, out)
+            elif L.num_stages > 1:
+                out = out.clone()     # eager outputs alias a workspace the next step overwrites
+
+        # ---- output ----------------------------------------------------------------------
+        result = None
+        if L.is_last:
+            result = out
+            if L.num_stages == 1:
+                self._local_fb[mb] = out
+            elif out.numel() > 0:
+                self._send_pending[mb] = L.fb_data.send(out)
+        else:
+            L.next_ctrl.put(desc.to_bytes())           # descriptor first: the next stage posts its recv
+            self._send_pending[mb] = L.next_data.send(out)
+        self.steps += 1
+        if self.board is not None:
+            self.board.beat(self.stage, 1, T, time.perf_counter_ns() - t_start)
+        if self.tracer is not None:
+            self.tracer.span(f"stage{self.stage}", "step", t_start, time.perf_counter_ns(),
+                             {"mb": mb, "tokens": T, "decode": desc.is_decode})
+        return result
+
+    def drain(self):
+        for h in self._send_pending.values():
+            try:
+                h.wait()
+            except Exception:
+                pass
+        self._send_pending.clear()
+        if self.on_gpu:
+            torch.cuda.synchronize(self.device)
+
+
+def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5) -> int:
+    """Blocking loop of a non-zero stage: descriptors in, steps out, until SHUTDOWN.
+    Returns the number of steps executed. Errors are recorded on the status board and re-raised."""
+    from .shm import ST_ERROR, ST_READY, ST_STOPPED, RingClosed
+    L, board = runtime.links, runtime.board
+    if board is not None:
+        board.set_state(runtime.stage, ST_READY)
+    try:
+        while True:
+            try:
+                msg = L.prev_ctrl.get(timeout_s=idle_beat_s)
+            except RingClosed:
+                break
+            if msg is None:
+                if board is not None:
+                    board.beat(runtime.stage)          # idle heartbeat
+                continue
+            desc = StepBatch.from_bytes(msg)
+            if desc.kind == KIND_SHUTDOWN:
+                if L.next_ctrl is not None:
+                    L.next_ctrl.put(msg)
+                break
+            runtime.execute(desc)
+    except BaseException as e:
+        if board is not None:
+            board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
+        traceback.print_exc()
+        raise
+    finally:
+        try:
+            runtime.drain()
+        except Exception:
+            pass
+    if board is not None:
+        board.set_state(runtime.stage, ST_STOPPED)
+    return runtime.steps

@@ -1,0 +1,271 @@
+"""Stage-to-stage data plane.
+
+The reference moves hidden states as JSON text over HTTP through a public tunnel, relayed by
+the orchestrator, the whole sequence on every hop (orchestration.py:114-137; Worker1.py:216-239).
+Here an `Edge` is one directed hop of the pipeline (stage i -> i+1, or the token feedback from
+the last stage to stage 0) and carries only the new tokens' rows:
+
+* `TorchDistEdge` — `torch.distributed` point-to-point. Backend "nccl" is RCCL on ROCm: the
+  buffer goes GPU-to-GPU over the xGMI link joining the two devices, enqueued on RCCL's own
+  stream and chained to the compute stream by events, so the host never blocks and hop *t*
+  overlaps the next micro-batch's compute. Backend "gloo" is the CPU path used by the tests.
+  Every edge gets its OWN 2-rank process group (own communicator, own stream): forward hops and
+  the feedback hop can never queue behind each other, which is what would deadlock a full
+  pipeline if they shared one in-order stream.
+* `LoopbackEdge` — in-process queues, for single-process pipelines in tests.
+* HTTP (`serving/worker.py`) keeps the reference's `/process` wire format for plumbing parity.
+
+An edge also carries the control messages (step descriptors) of its hop: over a shared-memory
+ring when both ends are on one node (`ShmControl`), or over gloo otherwise.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+
+class Handle:
+    """Completion of an async send/recv."""
+
+    def wait(self):          # make the current stream / the host observe completion
+        pass
+
+    def done(self) -> bool:
+        return True
+
+
+class _WorkHandle(Handle):
+    def __init__(self, work, keep=None):
+        self.work, self.keep = work, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def done(self) -> bool:
+        return self.work is None or self.work.is_completed()
+
+
+class _PolledWorkHandle(Handle):
+    """gloo point-to-point work never reports is_completed() until someone calls wait(), so
+    polling needs a helper thread that waits and raises a flag."""
+
+    def __init__(self, work, keep=None):
+        self.work, self.keep = work, keep
+        self._flag = threading.Event()
+        self._thread: Optional[threading.Thread] = None
+        self._err: Optional[BaseException] = None
+
+    def _run(self):
+        try:
+            self.work.wait()
+        except BaseException as e:      # surfaced by wait()
+            self._err = e
+        self._flag.set()
+
+    def _ensure(self):
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def wait(self):
+        self._ensure()
+        self._flag.wait()
+        if self._err is not None:
+            raise self._err
+
+    def done(self) -> bool:
+        self._ensure()
+        return self._flag.is_set()
+
+
+class Edge:
+    def send(self, t: torch.Tensor) -> Handle:
+        raise NotImplementedError
+
+    def recv(self, buf: torch.Tensor) -> Handle:
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------
+class LoopbackEdge(Edge):
+    def __init__(self):
+        self.q: "queue.Queue[torch.Tensor]" = queue.Queue()
+
+    def send(self, t):
+        self.q.put(t.detach().clone())
+        return Handle()
+
+    def recv(self, buf, timeout: float = 60.0):
+        t = self.q.get(timeout=timeout)
+        if t.numel() != buf.numel():
+            raise RuntimeError(f"loopback edge: expected {buf.numel()} elements, got {t.numel()}")
+        buf.copy_(t.reshape(buf.shape).to(buf.dtype))
+        return Handle()
+
+
+class TorchDistEdge(Edge):
+    """One directed hop src_rank -> dst_rank over its own 2-rank process group."""
+
+    def __init__(self, group, src_rank: int, dst_rank: int, my_rank: int):
+        self.group, self.src, self.dst, self.me = group, src_rank, dst_rank, my_rank
+
+    def send(self, t):
+        import torch.distributed as dist
+        assert self.me == self.src
+        t = t.contiguous()
+        cls = _WorkHandle if t.is_cuda else _PolledWorkHandle
+        return cls(dist.isend(t, self.dst, group=self.group), keep=t)
+
+    def recv(self, buf):
+        import torch.distributed as dist
+        assert self.me == self.dst
+        assert buf.is_contiguous()
+        cls = _WorkHandle if buf.is_cuda else _PolledWorkHandle
+        return cls(dist.irecv(buf, self.src, group=self.group))
+
+
+# ---------------------------------------------------------------------------------------------
+class Control:
+    """FIFO of small byte messages along one hop."""
+
+    def put(self, msg: bytes):
+        raise NotImplementedError
+
+    def get(self, timeout_s: Optional[float] = None) -> Optional[bytes]:
+        raise NotImplementedError
+
+    def close(self):
+        pass
+
+
+class QueueControl(Control):
+    def __init__(self):
+        self.q: "queue.Queue[bytes]" = queue.Queue()
+
+    def put(self, msg):
+        self.q.put(msg)
+
+    def get(self, timeout_s=None):
+        try:
+            return self.q.get(timeout=timeout_s)
+        except queue.Empty:
+            return None
+
+
+class ShmControl(Control):
+    def __init__(self, name: str, create: bool, slots: int = 512, slot_bytes: int = 1 << 17):
+        from .shm import ShmRing
+        self.ring = ShmRing(name, create, slots, slot_bytes)
+
+    def put(self, msg):
+        self.ring.put(msg, timeout_s=120.0)
+
+    def get(self, timeout_s=None):
+        return self.ring.get(timeout_s)
+
+    def close(self):
+        self.ring.close()
+
+
+class GlooControl(Control):
+    """Control messages as length-prefixed uint8 tensors over a gloo group (multi-node fallback)."""
+
+    def __init__(self, group, src_rank: int, dst_rank: int, my_rank: int):
+        self.group, self.src, self.dst, self.me = group, src_rank, dst_rank, my_rank
+
+    def put(self, msg):
+        import torch.distributed as dist
+        n = torch.tensor([len(msg)], dtype=torch.int64)
+        dist.send(n, self.dst, group=self.group)
+        dist.send(torch.frombuffer(bytearray(msg), dtype=torch.uint8), self.dst, group=self.group)
+
+    def get(self, timeout_s=None):
+        import torch.distributed as dist
+        n = torch.zeros(1, dtype=torch.int64)
+        dist.recv(n, self.src, group=self.group)
+        buf = torch.zeros(int(n.item()), dtype=torch.uint8)
+        dist.recv(buf, self.src, group=self.group)
+        return bytes(buf.numpy().tobytes())
+
+
+# ---------------------------------------------------------------------------------------------
+class PipelineLinks:
+    """Everything one stage needs to talk to its neighbours."""
+
+    def __init__(self, stage: int, num_stages: int):
+        self.stage, self.num_stages = stage, num_stages
+        self.prev_data: Optional[Edge] = None      # hidden states from stage-1
+        self.next_data: Optional[Edge] = None      # hidden states to stage+1
+        self.fb_data: Optional[Edge] = None        # tokens: last stage -> stage 0 (both ends hold it)
+        self.prev_ctrl: Optional[Control] = None   # descriptors from stage-1
+        self.next_ctrl: Optional[Control] = None   # descriptors to stage+1
+
+    @property
+    def is_first(self) -> bool:
+        return self.stage == 0
+
+    @property
+    def is_last(self) -> bool:
+        return self.stage == self.num_stages - 1
+
+    def close(self):
+        for x in (self.prev_data, self.next_data, self.fb_data, self.prev_ctrl, self.next_ctrl):
+            if x is not None:
+                try:
+                    x.close()
+                except Exception:
+                    pass
+
+
+def make_loopback_links(num_stages: int) -> List[PipelineLinks]:
+    links = [PipelineLinks(s, num_stages) for s in range(num_stages)]
+    for s in range(num_stages - 1):
+        e, c = LoopbackEdge(), QueueControl()
+        links[s].next_data, links[s + 1].prev_data = e, e
+        links[s].next_ctrl, links[s + 1].prev_ctrl = c, c
+    if num_stages > 1:
+        fb = LoopbackEdge()
+        links[0].fb_data = links[-1].fb_data = fb
+    return links
+
+
+def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl: bool = True) -> PipelineLinks:
+    """Process groups and control rings for rank `rank` of a `world`-stage pipeline.
+
+    `torch.distributed` must already be initialised (any backend; sub-groups are created with
+    `backend`). new_group() is collective over the default group, so every rank creates every
+    edge's group in the same order, then keeps only its own."""
+    import torch.distributed as dist
+    links = PipelineLinks(rank, world)
+    for s in range(world - 1):
+        g = dist.new_group(ranks=[s, s + 1], backend=backend)
+        if rank == s:
+            links.next_data = TorchDistEdge(g, s, s + 1, rank)
+        elif rank == s + 1:
+            links.prev_data = TorchDistEdge(g, s, s + 1, rank)
+    if world > 1:
+        g = dist.new_group(ranks=[0, world - 1], backend=backend)     # feedback hop, own communicator
+        if rank in (0, world - 1):
+            links.fb_data = TorchDistEdge(g, world - 1, 0, rank)
+    if use_shm_ctrl:
+        # producer creates, consumer attaches (with retry) — no ordering requirement between them
+        if rank < world - 1:
+            links.next_ctrl = ShmControl(f"{job}_c{rank}", create=True)
+        if rank > 0:
+            links.prev_ctrl = ShmControl(f"{job}_c{rank - 1}", create=False)
+    else:
+        for s in range(world - 1):
+            g = dist.new_group(ranks=[s, s + 1], backend="gloo")
+            if rank == s:
+                links.next_ctrl = GlooControl(g, s, s + 1, rank)
+            elif rank == s + 1:
+                links.prev_ctrl = GlooControl(g, s, s + 1, rank)
+    return links

@@ -64,7 +64,8 @@ class StepBatch:
 
     @property
     def is_decode(self) -> bool:
-        return all(q == 1 for q in self.q_lens)
+        """Single-token step (rows with q_len 0 are padding of a fixed-shape micro-batch)."""
+        return bool(self.q_lens) and all(q in (0, 1) for q in self.q_lens) and any(q == 1 for q in self.q_lens)
 
     @property
     def num_samples(self) -> int:
@@ -75,7 +76,8 @@ class StepBatch:
         for name in ("q_lens", "ctx_lens", "sample", "temperature", "top_k", "top_p", "seeds", "sample_steps"):
             if len(getattr(self, name)) != B:
                 raise ValueError(f"StepBatch.{name} has {len(getattr(self, name))} entries for {B} sequences")
-        if self.token_ids is not None and len(self.token_ids) != self.num_tokens:
+        if self.token_ids is not None and len(self.token_ids) != self.num_tokens and not (
+                self.is_decode and len(self.token_ids) == B):     # fixed-shape decode: one id per row
             raise ValueError("token_ids length must equal the number of new tokens")
         if len(self.table_slots) != len(self.table_blocks):
             raise ValueError("table_slots / table_blocks mismatch")

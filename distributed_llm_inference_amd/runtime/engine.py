@@ -1,0 +1,565 @@
+"""Request scheduler and generation driver (runs on pipeline rank 0).
+
+One thread owns all mutable serving state: the request queue, the KV block tables and the
+micro-batches. HTTP handlers only enqueue requests and wait on futures. (The reference runs
+`generate_with_sampling` directly inside Flask's threaded dev server on shared globals with no
+lock: orchestration.py:234,333,372.)
+
+Scheduling model — continuous batching over `num_micro_batches` fixed-shape micro-batches:
+
+* a request is admitted into a free row of a micro-batch (KV blocks reserved for prompt +
+  max_new_tokens), prefilled in chunks of at most `prefill_chunk` tokens, then joins the
+  micro-batch's decode steps;
+* steady-state decode steps are "replays": the token fed to stage 0 is the one the last stage
+  sampled for that row (device-to-device feedback), context lengths and RNG counters advance
+  on the device, and up to `max_inflight_steps` steps of a micro-batch are issued before their
+  results are read — so with >= pp_size micro-batches in flight every stage always has work,
+  which is what removes the pipeline bubble the reference has by construction (one request,
+  strictly sequential hops: orchestration.py:109-137);
+* a micro-batch is recomposed (drained, finished rows retired, waiting requests admitted and
+  prefilled) only when that is worth a bubble: waiting work and free/dead rows, or all rows dead.
+
+The autoregressive semantics are the reference's (orchestration.py:69-228): stop at EOS without
+emitting it, cap at max_new_tokens, temperature/top-k/top-p sampling; and so is the result
+dictionary of `generate_text` (orchestration.py:211-218) and its error envelope (:220-228).
+"""
+from __future__ import annotations
+
+import collections
+import threading
+import time
+import traceback
+from dataclasses import dataclass, field
+from typing import Deque, Dict, List, Optional
+
+import torch
+
+from ..config import EngineConfig
+from ..parallel.pipeline import StageRuntime
+from ..parallel.transport import Handle
+from .batch import KIND_RELEASE, KIND_SHUTDOWN, StepBatch, control
+from .kv_cache import BlockAllocator, blocks_for
+from .sampler import SamplingParams
+from .tokenizer import build_prompt
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+@dataclass
+class Request:
+    rid: int
+    prompt_ids: List[int]
+    params: SamplingParams
+    eos_id: Optional[int]
+    t_arrival: float = field(default_factory=time.perf_counter)
+    state: str = "waiting"            # waiting | prefill | running | finished | failed
+    mb: int = -1
+    row: int = -1
+    slot: int = -1
+    blocks: List[int] = field(default_factory=list)
+    prefilled: int = 0                # prompt tokens submitted so far
+    issued_ctx: int = 0               # tokens whose KV the submitted steps (will) have cached
+    issued_samples: int = 0           # sampling steps submitted
+    output: List[int] = field(default_factory=list)
+    token_times: List[float] = field(default_factory=list)
+    t_first: float = 0.0
+    t_done: float = 0.0
+    error: Optional[str] = None
+    done: threading.Event = field(default_factory=threading.Event)
+    seed: int = 0
+
+    @property
+    def finished(self) -> bool:
+        return self.state in ("finished", "failed")
+
+    def wait(self, timeout: Optional[float] = None) -> "Request":
+        if not self.done.wait(timeout):
+            raise TimeoutError(f"request {self.rid} timed out after {timeout}s")
+        return self
+
+
+class _Result:
+    """Tokens of one submitted step, on their way to the host."""
+
+    def __init__(self, desc: StepBatch, rows: List[Optional[Request]], tokens=None, event=None,
+                 handle: Optional[Handle] = None, host=None, gpu_handle: Optional[Handle] = None):
+        self.desc, self.rows = desc, rows
+        self.tokens, self.event, self.handle, self.host = tokens, event, handle, host
+        self.gpu_handle = gpu_handle         # what the next step of this micro-batch must wait for
+        self.t_submit = time.perf_counter()
+
+    def ready(self) -> bool:
+        if self.event is not None:
+            return self.event.query()
+        if self.handle is not None:
+            return self.handle.done()
+        return True
+
+    def get(self) -> List[int]:
+        if self.event is not None:
+            self.event.synchronize()
+            return self.host.tolist()
+        if self.handle is not None:
+            self.handle.wait()
+        return self.tokens.tolist() if self.tokens is not None else []
+
+
+class _EventHandle(Handle):
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+    def done(self) -> bool:
+        return self.event.query()
+
+
+class _MicroBatch:
+    def __init__(self, idx: int, size: int):
+        self.idx = idx
+        self.rows: List[Optional[Request]] = [None] * size
+        self.inflight: Deque[_Result] = collections.deque()
+        self.state = "idle"           # idle | steady | draining | prefill
+        self.fresh: List[Request] = []    # admitted, prefill not finished
+        self.last_fb: Optional[Handle] = None
+
+    def live(self) -> List[Request]:
+        return [r for r in self.rows if r is not None and r.state == "running"]
+
+    def dead_rows(self) -> int:
+        return sum(1 for r in self.rows if r is not None and r.finished)
+
+    def free_rows(self) -> int:
+        return sum(1 for r in self.rows if r is None)
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig, runtime: StageRuntime, tokenizer, num_blocks: int,
+                 board=None, tracer=None):
+        self.cfg, self.rt, self.tok = cfg, runtime, tokenizer
+        self.spec = runtime.ex.spec
+        self.links = runtime.links
+        self.board, self.tracer = board, tracer
+        self.alloc = BlockAllocator(num_blocks)
+        self.mbs = [_MicroBatch(i, cfg.max_batch) for i in range(cfg.num_micro_batches)]
+        self.waiting: Deque[Request] = collections.deque()
+        self._inbox: Deque[Request] = collections.deque()
+        self._lock = threading.Lock()
+        self._wake = threading.Event()
+        self._stop = False
+        self._thread: Optional[threading.Thread] = None
+        self._rid = 0
+        self._step_id = 0
+        self.fatal: Optional[str] = None
+        self.on_gpu = runtime.on_gpu
+        self._res_stream = torch.cuda.Stream(device=runtime.device) if self.on_gpu else None
+        self._rr = 0
+        # counters for /metrics
+        self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
+                      "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0}
+        self.latencies: Deque[float] = collections.deque(maxlen=4096)     # per-token decode latencies (s)
+        self.ttfts: Deque[float] = collections.deque(maxlen=1024)
+
+    # ---- lifecycle -------------------------------------------------------------------------
+    def start(self):
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._loop, name="dlia-scheduler", daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self, timeout: float = 10.0):
+        self._stop = True
+        self._wake.set()
+        if self._thread is not None:
+            self._thread.join(timeout)
+            self._thread = None
+        try:
+            if self.links.next_ctrl is not None:
+                self.links.next_ctrl.put(control(KIND_SHUTDOWN).to_bytes())
+        except Exception:
+            pass
+        self.rt.drain()
+
+    # ---- public API ------------------------------------------------------------------------
+    def submit(self, prompt_ids: List[int], params: Optional[SamplingParams] = None) -> Request:
+        params = params or SamplingParams(self.cfg.temperature, self.cfg.top_k, self.cfg.top_p,
+                                          self.cfg.default_max_tokens)
+        with self._lock:
+            self._rid += 1
+            rid = self._rid
+        eos = getattr(self.tok, "eos_token_id", None)
+        if eos is None:
+            eos = self.spec.eos_token_id
+        req = Request(rid=rid, prompt_ids=list(prompt_ids), params=params, eos_id=eos)
+        req.seed = params.seed if params.seed is not None else (time.time_ns() ^ (rid * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
+        if self.fatal:
+            self._fail(req, self.fatal)
+            return req
+        if len(req.prompt_ids) == 0:
+            self._fail(req, "empty prompt")
+            return req
+        if len(req.prompt_ids) + 1 > self.cfg.max_seq_len:
+            self._fail(req, f"prompt of {len(req.prompt_ids)} tokens exceeds max_seq_len {self.cfg.max_seq_len}")
+            return req
+        self.stats["requests"] += 1
+        self.stats["tokens_in"] += len(req.prompt_ids)
+        self._inbox.append(req)
+        self._wake.set()
+        return req
+
+    def generate_text(self, prompt: str, max_new_tokens: Optional[int] = None, temperature: Optional[float] = None,
+                      top_k: Optional[int] = None, top_p: Optional[float] = None, seed: Optional[int] = None,
+                      timeout: Optional[float] = None) -> Dict:
+        """Prompt in, text out, with the reference's result / error dictionaries
+        (orchestration.py:211-228)."""
+        start = time.time()
+        try:
+            text = build_prompt(self.tok, prompt, self.cfg.system_prompt, self.cfg.chat_template)
+            ids = self.tok.encode(text)
+            n = self.cfg.default_max_tokens if max_new_tokens is None else int(max_new_tokens)
+            n = max(1, min(n, self.cfg.max_tokens_cap))
+            sp = SamplingParams(temperature=self.cfg.temperature if temperature is None else float(temperature),
+                                top_k=self.cfg.top_k if top_k is None else int(top_k),
+                                top_p=self.cfg.top_p if top_p is None else float(top_p),
+                                max_new_tokens=n, seed=seed)
+            req = self.submit(ids, sp).wait(timeout or self.cfg.request_timeout_s)
+            if req.state == "failed":
+                raise EngineError(req.error or "generation failed")
+            generated_text = self.tok.decode(req.output, skip_special_tokens=True)
+            elapsed = time.time() - start
+            tps = len(req.output) / elapsed if elapsed > 0 else 0
+            out = {"prompt": prompt, "response": generated_text, "status": "success",
+                   "time_taken": f"{elapsed:.2f}s", "tokens_generated": len(req.output),
+                   "tokens_per_sec": f"{tps:.2f}"}
+            # numeric extras (the reference's three metrics above are strings)
+            out["ttft_ms"] = round((req.t_first - req.t_arrival) * 1e3, 3) if req.t_first else None
+            if len(req.token_times) > 1:
+                gaps = sorted(b - a for a, b in zip(req.token_times, req.token_times[1:]))
+                out["tpot_ms_p50"] = round(gaps[len(gaps) // 2] * 1e3, 3)
+            if self.cfg.debug_top5:
+                out["token_ids"] = list(req.output)
+            return out
+        except Exception as e:      # same envelope as the reference: HTTP 200, status "failed"
+            return {"error": f"Error: {e}", "status": "failed"}
+
+    # ---- scheduler thread ------------------------------------------------------------------
+    def _loop(self):
+        try:
+            while not self._stop:
+                progressed = False
+                while self._inbox:
+                    self.waiting.append(self._inbox.popleft())
+                    progressed = True
+                n = len(self.mbs)
+                for i in range(n):
+                    mb = self.mbs[(self._rr + i) % n]
+                    progressed |= self._tick(mb)
+                self._rr = (self._rr + 1) % n
+                self._check_pipeline()
+                if not progressed:
+                    busy = any(mb.inflight or mb.state != "idle" for mb in self.mbs) or self.waiting
+                    if busy:
+                        time.sleep(20e-6)
+                    else:
+                        self._wake.wait(0.05)
+                        self._wake.clear()
+        except BaseException as e:
+            traceback.print_exc()
+            self._fatal(f"{type(e).__name__}: {e}")
+
+    def _check_pipeline(self):
+        """Watchdog: a stage that died or reported an error fails everything in flight."""
+        if self.board is None or self.links.num_stages == 1:
+            return
+        now = time.perf_counter()
+        if now - getattr(self, "_last_check", 0.0) < 0.25:
+            return
+        self._last_check = now
+        import os
+        for s in range(1, self.links.num_stages):
+            st = self.board.read(s)
+            dead = False
+            if st["state"] == "error":
+                dead = True
+                why = f"stage {s} failed: {st['error']}"
+            elif st["state"] in ("ready", "starting") and st["pid"] > 0:
+                try:
+                    os.kill(st["pid"], 0)
+                except ProcessLookupError:
+                    dead, why = True, f"stage {s} (pid {st['pid']}) is gone"
+                except PermissionError:
+                    pass
+            if not dead and any(mb.inflight for mb in self.mbs):
+                oldest = min(r.t_submit for mb in self.mbs for r in mb.inflight)
+                if now - oldest > self.cfg.hop_timeout_s * self.links.num_stages:
+                    dead, why = True, f"pipeline stalled: no result for {now - oldest:.1f}s"
+            if dead:
+                raise EngineError(why)
+
+    def _fatal(self, msg: str):
+        self.fatal = msg
+        for mb in self.mbs:
+            for r in mb.rows:
+                if r is not None and not r.finished:
+                    self._fail(r, msg)
+            mb.inflight.clear()
+        for r in list(self.waiting) + list(self._inbox):
+            self._fail(r, msg)
+        self.waiting.clear()
+
+    def _fail(self, req: Request, msg: str):
+        req.error, req.state = msg, "failed"
+        req.t_done = time.perf_counter()
+        self.stats["failed"] += 1
+        req.done.set()
+
+    # ---- per-micro-batch state machine -----------------------------------------------------
+    def _tick(self, mb: _MicroBatch) -> bool:
+        progressed = False
+        while mb.inflight and mb.inflight[0].ready():
+            self._harvest(mb, mb.inflight.popleft())
+            progressed = True
+
+        if mb.state == "idle":
+            if self.waiting:
+                mb.state = "draining"
+            else:
+                return progressed
+
+        if mb.state == "steady":
+            live = mb.live()
+            waiting_fits = bool(self.waiting) and (mb.free_rows() + mb.dead_rows() > 0)
+            if not live or waiting_fits or mb.dead_rows() * 2 >= max(1, len(live) + mb.dead_rows()):
+                mb.state = "draining"
+            elif len(mb.inflight) < self.cfg.max_inflight_steps and self._budget_left(mb):
+                self._submit_decode(mb, replay=True)
+                return True
+
+        if mb.state == "draining":
+            if mb.inflight:
+                return progressed
+            self._retire(mb)
+            self._admit(mb)
+            if mb.fresh:
+                mb.state = "prefill"
+            elif mb.live():
+                self._submit_decode(mb, replay=False)
+                mb.state = "steady"
+                return True
+            else:
+                mb.state = "idle"
+                return True
+
+        if mb.state == "prefill":
+            if mb.inflight:
+                return progressed
+            pending = [r for r in mb.fresh if r.prefilled < len(r.prompt_ids) and not r.finished]
+            if pending:
+                self._submit_prefill(mb, pending)
+                return True
+            mb.fresh = []
+            if mb.live():
+                self._submit_decode(mb, replay=False)
+                mb.state = "steady"
+            else:
+                mb.state = "draining"
+            return True
+        return progressed
+
+    def _budget_left(self, mb: _MicroBatch) -> bool:
+        """Is there a row that still needs tokens beyond what is already in flight?"""
+        for r in mb.live():
+            if r.issued_samples < r.params.max_new_tokens and r.issued_ctx + 1 <= self.cfg.max_seq_len:
+                return True
+        return False
+
+    def _retire(self, mb: _MicroBatch):
+        gone = []
+        for i, r in enumerate(mb.rows):
+            if r is not None and r.finished:
+                self.alloc.release(r.rid)
+                gone.append(r.slot)
+                mb.rows[i] = None
+        if gone:
+            self.stats["recompositions"] += 1
+            self._dispatch(control(KIND_RELEASE, gone))
+
+    def _admit(self, mb: _MicroBatch):
+        while self.waiting and mb.free_rows() > 0:
+            req = self.waiting[0]
+            total = min(len(req.prompt_ids) + req.params.max_new_tokens, self.cfg.max_seq_len)
+            blocks = self.alloc.take(req.rid, blocks_for(total))
+            if blocks is None:
+                if self.alloc.used == 0:
+                    self.waiting.popleft()
+                    self._fail(req, "request needs more KV blocks than the cache holds")
+                    continue
+                break                      # wait for running requests to free blocks
+            self.waiting.popleft()
+            row = mb.rows.index(None)
+            req.mb, req.row, req.slot = mb.idx, row, mb.idx * self.cfg.max_batch + row
+            req.blocks, req.state = blocks, "prefill"
+            mb.rows[row] = req
+            mb.fresh.append(req)
+
+    # ---- step construction -------------------------------------------------------------------
+    def _next_step_id(self) -> int:
+        self._step_id += 1
+        return self._step_id
+
+    def _submit_prefill(self, mb: _MicroBatch, pending: List[Request]):
+        budget = self.cfg.prefill_chunk
+        d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, token_ids=[])
+        rows: List[Optional[Request]] = []
+        for r in pending:
+            if budget <= 0 or len(d.slots) >= self.cfg.max_batch:
+                break
+            n = min(len(r.prompt_ids) - r.prefilled, budget)
+            last = r.prefilled + n == len(r.prompt_ids)
+            d.slots.append(r.slot); d.q_lens.append(n); d.ctx_lens.append(r.prefilled)
+            d.sample.append(1 if last else 0)
+            d.temperature.append(r.params.temperature); d.top_k.append(r.params.top_k); d.top_p.append(r.params.top_p)
+            d.seeds.append(r.seed); d.sample_steps.append(0)
+            d.token_ids += r.prompt_ids[r.prefilled:r.prefilled + n]
+            if r.prefilled == 0:
+                d.table_slots.append(r.slot); d.table_blocks.append(list(r.blocks))
+            r.prefilled += n
+            r.issued_ctx = r.prefilled
+            if last:
+                r.issued_samples = 1
+                rows.append(r)
+            budget -= n
+        self.stats["prefill_steps"] += 1
+        self._submit(mb, d, rows)
+
+    def _submit_decode(self, mb: _MicroBatch, replay: bool):
+        d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, replay=replay,
+                      token_ids=None if replay else [])
+        rows: List[Optional[Request]] = []
+        for i, r in enumerate(mb.rows):
+            live = r is not None and r.state == "running"
+            # fixed shape: every row of the micro-batch is present, dead/empty ones as padding
+            d.slots.append(r.slot if r is not None else mb.idx * self.cfg.max_batch + i)
+            d.q_lens.append(1 if live else 0)
+            d.ctx_lens.append(r.issued_ctx if live else 0)
+            d.sample.append(1 if live else 0)
+            d.temperature.append(r.params.temperature if live else 0.0)
+            d.top_k.append(r.params.top_k if live else 1)
+            d.top_p.append(r.params.top_p if live else 1.0)
+            d.seeds.append(r.seed if live else 0)
+            d.sample_steps.append(r.issued_samples if live else 0)
+            if live:
+                if not replay:
+                    d.token_ids.append(r.output[-1] if r.output else 0)
+                r.issued_ctx += 1
+                r.issued_samples += 1
+            rows.append(r if live else None)
+        if not replay and self.rt._graph_decode(d):
+            # static-buffer decode wants one token per row, padding rows included
+            toks, it = [], iter(d.token_ids)
+            for q in d.q_lens:
+                toks.append(next(it) if q == 1 else 0)
+            d.token_ids = toks
+        self.stats["decode_steps"] += 1
+        self._submit(mb, d, rows)
+
+    def _dispatch(self, d: StepBatch):
+        self.rt.execute(d)
+
+    def _submit(self, mb: _MicroBatch, d: StepBatch, rows: List[Optional[Request]]):
+        d.validate()
+        self.stats["steps"] += 1
+        n_res = self.rt.result_count(d)
+        fb_wait = mb.last_fb if d.token_ids is None else None
+        if self.on_gpu and getattr(mb, "last_copy", None) is not None:
+            # the previous step's tokens must have left the static buffer before it is rewritten
+            torch.cuda.current_stream().wait_event(mb.last_copy)
+        tokens = self.rt.execute(d, fb_wait)
+        res = None
+        if self.links.num_stages == 1:
+            if self.on_gpu:
+                host = torch.empty(n_res, dtype=torch.int32).pin_memory() if n_res else torch.empty(0, dtype=torch.int32)
+                ev = torch.cuda.Event()
+                done = torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(self._res_stream):
+                    self._res_stream.wait_event(done)
+                    if n_res:
+                        host.copy_(tokens, non_blocking=True)
+                    ev.record()
+                mb.last_copy = ev
+                res = _Result(d, rows, event=ev, host=host)
+            else:
+                res = _Result(d, rows, tokens=tokens)
+        else:
+            buf = self.rt.fb_buffer(mb.idx, n_res)
+            if self.on_gpu:
+                host = torch.empty(n_res, dtype=torch.int32).pin_memory()
+                ev, got = torch.cuda.Event(), torch.cuda.Event()
+                with torch.cuda.stream(self._res_stream):
+                    h = self.links.fb_data.recv(buf) if n_res else None
+                    if h is not None:
+                        h.wait()
+                    got.record()
+                    if n_res:
+                        host.copy_(buf, non_blocking=True)
+                    ev.record()
+                mb.last_fb = _EventHandle(got)
+                res = _Result(d, rows, event=ev, host=host)
+            else:
+                h = self.links.fb_data.recv(buf) if n_res else None
+                mb.last_fb = h
+                res = _Result(d, rows, tokens=buf, handle=h)
+        mb.inflight.append(res)
+
+    # ---- results -------------------------------------------------------------------------------
+    def _harvest(self, mb: _MicroBatch, res: _Result):
+        toks = res.get()
+        now = time.perf_counter()
+        d = res.desc
+        per_row = self.rt._graph_decode(d)
+        k = 0
+        for i, r in enumerate(res.rows):
+            if per_row:
+                tok = toks[i] if i < len(toks) else 0
+            else:
+                if r is None:
+                    continue
+                tok = toks[k] if k < len(toks) else 0
+                k += 1
+            if r is None or r.finished:
+                continue
+            self._on_token(r, int(tok), now)
+
+    def _on_token(self, r: Request, tok: int, now: float):
+        if r.state == "prefill":
+            r.state = "running"
+            r.t_first = now
+            self.ttfts.append(now - r.t_arrival)
+        elif r.token_times:
+            self.latencies.append(now - r.token_times[-1])
+        if r.params.stop_on_eos and r.eos_id is not None and tok == r.eos_id:
+            self._finish(r, now)          # EOS is not emitted (orchestration.py:181-183)
+            return
+        r.output.append(tok)
+        r.token_times.append(now)
+        self.stats["tokens_out"] += 1
+        if len(r.output) >= r.params.max_new_tokens or len(r.prompt_ids) + len(r.output) >= self.cfg.max_seq_len:
+            self._finish(r, now)
+
+    def _finish(self, r: Request, now: float):
+        r.state, r.t_done = "finished", now
+        self.stats["completed"] += 1
+        r.done.set()
+
+    # ---- introspection -----------------------------------------------------------------------
+    def snapshot(self) -> Dict:
+        lat = sorted(self.latencies)
+        p = lambda q: lat[min(len(lat) - 1, int(q * len(lat)))] * 1e3 if lat else None
+        return {**self.stats, "waiting": len(self.waiting) + len(self._inbox),
+                "running": sum(len(mb.live()) for mb in self.mbs),
+                "kv_blocks_used": self.alloc.used, "kv_blocks_total": self.alloc.num_blocks,
+                "tpot_ms_p50": p(0.5), "tpot_ms_p99": p(0.99), "fatal": self.fatal}

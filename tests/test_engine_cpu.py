@@ -1,0 +1,192 @@
+"""Scheduler + pipeline runtime on CPU: PP=1 vs PP=2/4 equivalence over loopback links, ragged
+batches, chunked prefill, continuous batching, EOS / token-cap semantics, and a real
+multi-process 2-stage pipeline over gloo with shared-memory control rings."""
+import threading
+
+import pytest
+import torch
+
+from distributed_llm_inference_amd.config import EngineConfig
+from distributed_llm_inference_amd.models.partition import make_plans
+from distributed_llm_inference_amd.models.spec import BUILTIN_SPECS, tiny_spec
+from distributed_llm_inference_amd.models.stage_ref import RefStage
+from distributed_llm_inference_amd.models.weights import random_stage_weights
+from distributed_llm_inference_amd.parallel.launcher import LocalPipeline, make_pipeline
+from distributed_llm_inference_amd.runtime.sampler import SamplingParams
+
+from helpers import hf_model_from
+
+SPEC = tiny_spec("llama")
+
+
+def cfg(**kw):
+    base = dict(model="tiny-llama-test", pp_size=1, max_batch=4, num_micro_batches=2, max_seq_len=128,
+                prefill_chunk=16, backend="torch", device="cpu", transport="loopback", seed=7)
+    base.update(kw)
+    return EngineConfig(**base)
+
+
+def greedy(n=8, **kw):
+    return SamplingParams(temperature=0.0, top_k=50, top_p=0.9, max_new_tokens=n, stop_on_eos=False, **kw)
+
+
+def run(pipe, prompts, params):
+    reqs = [pipe.engine.submit(p, params) for p in prompts]
+    return [r.wait(60).output for r in reqs]
+
+
+def prompts(n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(3, SPEC.vocab_size, (int(torch.randint(3, 40, (1,), generator=g)),), generator=g).tolist()
+            for _ in range(n)]
+
+
+def hf_greedy(prompt, n):
+    hf = hf_model_from(SPEC, seed=7)
+    ids = torch.tensor([prompt])
+    out = []
+    with torch.no_grad():
+        for _ in range(n):
+            nxt = int(hf(ids).logits[0, -1].argmax())      # full recompute, as the reference does
+            out.append(nxt)
+            ids = torch.cat([ids, torch.tensor([[nxt]])], 1)
+    return out
+
+
+def test_single_request_matches_transformers_full_recompute():
+    pipe = LocalPipeline(cfg())
+    try:
+        p = prompts(1)[0]
+        got = run(pipe, [p], greedy(10))[0]
+        assert got == hf_greedy(p, 10)
+    finally:
+        pipe.close()
+
+
+@pytest.mark.parametrize("pp", [2, 4])
+def test_pipeline_equals_single_stage(pp):
+    ps = prompts(11, seed=pp)
+    one = LocalPipeline(cfg())
+    try:
+        want = run(one, ps, greedy(9))
+    finally:
+        one.close()
+    many = LocalPipeline(cfg(pp_size=pp, num_micro_batches=pp, partition="even"))
+    try:
+        got = run(many, ps, greedy(9))
+        assert got == want
+        st = many.engine.snapshot()
+        assert st["completed"] == 11 and st["kv_blocks_used"] >= 0
+        assert many.board.read(pp - 1)["steps"] > 0          # the last stage really ran
+    finally:
+        many.close()
+
+
+def test_uneven_and_explicit_partitions_agree():
+    ps = prompts(3, seed=5)
+    outs = []
+    for kw in (dict(pp_size=1), dict(pp_size=3, num_micro_batches=3, partition="balanced"),
+               dict(pp_size=2, num_micro_batches=2, layer_ranges=[(0, 1), (1, 4)])):
+        pipe = LocalPipeline(cfg(**kw))
+        try:
+            outs.append(run(pipe, ps, greedy(6)))
+        finally:
+            pipe.close()
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_batched_equals_unbatched_and_chunked_prefill():
+    ps = prompts(6, seed=9)
+    ps[0] = (ps[0] * 4)[:70]                 # longer than prefill_chunk=16 -> several chunks
+    a = LocalPipeline(cfg(max_batch=1, num_micro_batches=1))
+    try:
+        want = [run(a, [p], greedy(7))[0] for p in ps]
+    finally:
+        a.close()
+    b = LocalPipeline(cfg(max_batch=4, num_micro_batches=2))
+    try:
+        assert run(b, ps, greedy(7)) == want
+        assert b.engine.stats["prefill_steps"] >= 5
+    finally:
+        b.close()
+
+
+def test_eos_stops_without_emitting_and_token_cap():
+    pipe = LocalPipeline(cfg())
+    try:
+        p = prompts(1, seed=3)[0]
+        free_run = run(pipe, [p], greedy(12))[0]
+        eos = free_run[4]
+        pipe.engine.tok.eos_token_id = eos            # make the 5th token the EOS
+        r = pipe.engine.submit(p, SamplingParams(temperature=0.0, max_new_tokens=12)).wait(60)
+        first = free_run.index(eos)
+        assert r.output == free_run[:first] and eos not in r.output
+        r2 = pipe.engine.submit(p, greedy(3)).wait(60)
+        assert len(r2.output) == 3
+    finally:
+        pipe.close()
+
+
+def test_seeded_sampling_is_reproducible_and_batch_invariant():
+    pipe = LocalPipeline(cfg())
+    try:
+        p = prompts(1, seed=4)[0]
+        sp = SamplingParams(temperature=0.9, top_k=20, top_p=0.95, max_new_tokens=8, seed=1234, stop_on_eos=False)
+        a = pipe.engine.submit(p, sp).wait(60).output
+        others = [pipe.engine.submit(q, greedy(5)) for q in prompts(5, seed=8)]
+        b = pipe.engine.submit(p, sp).wait(60).output
+        [o.wait(60) for o in others]
+        assert a == b
+    finally:
+        pipe.close()
+
+
+def test_more_requests_than_rows_continuous_batching():
+    pipe = LocalPipeline(cfg(max_batch=2, num_micro_batches=2))
+    try:
+        ps = prompts(13, seed=11)
+        lens = [3 + (i % 5) for i in range(13)]
+        reqs = [pipe.engine.submit(p, greedy(n)) for p, n in zip(ps, lens)]
+        outs = [r.wait(120).output for r in reqs]
+        assert [len(o) for o in outs] == lens
+        solo = LocalPipeline(cfg(max_batch=1, num_micro_batches=1))
+        try:
+            for p, n, o in list(zip(ps, lens, outs))[:4]:
+                assert run(solo, [p], greedy(n))[0] == o
+        finally:
+            solo.close()
+        snap = pipe.engine.snapshot()
+        assert snap["completed"] == 13 and snap["recompositions"] >= 1
+        assert pipe.engine.alloc.used <= 4 * pipe.engine.alloc.num_blocks
+    finally:
+        pipe.close()
+
+
+def test_generate_text_result_schema_and_failure_envelope():
+    pipe = LocalPipeline(cfg(model="tiny-gpt2-test"))
+    try:
+        out = pipe.engine.generate_text("Hello", max_new_tokens=5, temperature=0.7)
+        assert out["status"] == "success" and out["prompt"] == "Hello"
+        assert out["time_taken"].endswith("s") and isinstance(out["tokens_generated"], int)
+        float(out["tokens_per_sec"])
+        assert 0 <= out["tokens_generated"] <= 5
+        bad = pipe.engine.generate_text("x" * 5000, max_new_tokens=5)
+        assert bad["status"] == "failed" and bad["error"].startswith("Error: ")
+    finally:
+        pipe.close()
+
+
+def test_multiprocess_gloo_pipeline_matches_local():
+    ps = prompts(5, seed=21)
+    one = LocalPipeline(cfg())
+    try:
+        want = run(one, ps, greedy(6))
+    finally:
+        one.close()
+    pipe = make_pipeline(cfg(pp_size=2, num_micro_batches=2, transport="gloo", partition="even"))
+    try:
+        assert run(pipe, ps, greedy(6)) == want
+        states = [pipe.board.read(s) for s in range(2)]
+        assert states[1]["state"] == "ready" and states[1]["steps"] > 0 and states[1]["layers"] == "2-4"
+    finally:
+        pipe.close()
