@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: output tokens/sec (whole node) and p50 per-token latency of Llama-3-8B
+layer-split over N pipeline stages (PP = N GPUs of one node), bf16, synthetic prompts,
+random-init weights.
+
+    python bench.py --gpus 1 --steps 32 --warmup 4
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One rank per GPU; rank = pipeline stage; hidden states hop stage to stage over RCCL send/recv,
+sampled token ids hop back from the last stage to stage 0. A "step" is one decode step of EVERY
+in-flight sequence: each of the 2N micro-batches (64 sequences each) goes once through all N
+stages — embedding, every decoder layer against the paged KV cache, final norm, lm_head,
+temperature/top-k/top-p sampling, token feedback. Per-GPU work per step is constant in N (2N
+micro-batches x L/N layers), i.e. weak scaling. Prefill of the synthetic prompts and W warm-up
+steps run first; then exactly K steps are timed between barrier + device-synchronize brackets,
+the MAX over ranks is taken, and rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from distributed_llm_inference_amd.config import EngineConfig                        # noqa: E402
+from distributed_llm_inference_amd.parallel.launcher import attach_distributed       # noqa: E402
+from distributed_llm_inference_amd.parallel.pipeline import stage_main               # noqa: E402
+from distributed_llm_inference_amd.runtime.batch import (KIND_BARRIER, KIND_SHUTDOWN,  # noqa: E402
+                                                         StepBatch, control)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--batch", type=int, default=64, help="sequences per micro-batch")
+    ap.add_argument("--micro-batches", type=int, default=0, help="in-flight micro-batches (default 2 x gpus)")
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--partition", default="balanced")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU (torch backend, gloo)")
+    return ap.parse_args()
+
+
+def baseline_for(model: str):
+    """Reference-path throughput (tok/s) recorded in BASELINE.md for this model, if measured."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench", "baseline_numbers.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(model, {}).get("tokens_per_sec")
+    except Exception:
+        return None
+
+
+class Driver:
+    """Rank 0: issues the static benchmark schedule through its own StageRuntime."""
+
+    def __init__(self, rt, cfg, args):
+        self.rt, self.cfg, self.a = rt, cfg, args
+        self.links = rt.links
+        self.B = cfg.max_batch
+        self.nmb = cfg.num_micro_batches
+        self.on_gpu = rt.on_gpu
+        self.res_stream = torch.cuda.Stream(device=rt.device) if self.on_gpu else None
+        self.fb = [None] * self.nmb
+        self.step_id = 0
+        self.lat_events = [[] for _ in range(self.nmb)]
+        self.blocks_per_seq = (cfg.max_seq_len + 31) // 32
+
+    def _desc(self, mb, q_lens, ctx_lens, sample, token_ids, replay=False, tables=False):
+        B = self.B
+        slots = [mb * B + i for i in range(B)]
+        self.step_id += 1
+        d = StepBatch(step_id=self.step_id, micro_batch=mb, slots=slots[:len(q_lens)], q_lens=q_lens,
+                      ctx_lens=ctx_lens, sample=sample, temperature=[0.7] * len(q_lens), top_k=[50] * len(q_lens),
+                      top_p=[0.9] * len(q_lens), seeds=[1000 + s for s in slots[:len(q_lens)]],
+                      sample_steps=[0] * len(q_lens), token_ids=token_ids, replay=replay)
+        return d
+
+    def prefill(self):
+        a, B = self.a, self.B
+        g = torch.Generator().manual_seed(0)
+        vocab = self.rt.ex.spec.vocab_size
+        per_step = max(1, self.cfg.prefill_chunk // a.prompt_len)
+        for mb in range(self.nmb):
+            for s0 in range(0, B, per_step):
+                n = min(per_step, B - s0)
+                slots = [mb * B + s0 + i for i in range(n)]
+                self.step_id += 1
+                toks = torch.randint(10, vocab - 10, (n * a.prompt_len,), generator=g).tolist()
+                d = StepBatch(step_id=self.step_id, micro_batch=mb, slots=slots, q_lens=[a.prompt_len] * n,
+                              ctx_lens=[0] * n, sample=[0] * n, temperature=[0.7] * n, top_k=[50] * n,
+                              top_p=[0.9] * n, seeds=slots, sample_steps=[0] * n, token_ids=toks,
+                              table_slots=slots,
+                              table_blocks=[list(range(s * self.blocks_per_seq, (s + 1) * self.blocks_per_seq))
+                                            for s in slots])
+                self.rt.execute(d)
+
+    def decode_round(self, first: bool, ctx: int, record: bool = False):
+        B = self.B
+        for mb in range(self.nmb):
+            if first:
+                d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, [(7 * (mb * B + i)) % 1000 + 10 for i in range(B)])
+                fbw = None
+            else:
+                d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, None, replay=True)
+                fbw = self.fb[mb]
+            toks = self.rt.execute(d, fbw)
+            n = self.rt.result_count(d)
+            if self.links.num_stages > 1:
+                buf = self.rt.fb_buffer(mb, n)
+                if self.on_gpu:
+                    got = torch.cuda.Event(enable_timing=record)
+                    with torch.cuda.stream(self.res_stream):
+                        self.links.fb_data.recv(buf).wait()
+                        got.record()
+                    self.fb[mb] = _EvHandle(got)
+                    if record:
+                        self.lat_events[mb].append(got)
+                else:
+                    self.fb[mb] = self.links.fb_data.recv(buf)
+                    if record:
+                        self.fb[mb].wait()
+                        self.lat_events[mb].append(time.perf_counter())
+            else:
+                if self.on_gpu and record:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.lat_events[mb].append(ev)
+                elif record:
+                    self.lat_events[mb].append(time.perf_counter())
+
+    def barrier(self):
+        self.rt.execute(control(KIND_BARRIER))
+
+    def latencies_ms(self):
+        out = []
+        for evs in self.lat_events:
+            for a, b in zip(evs, evs[1:]):
+                out.append(a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3)
+        return sorted(out)
+
+
+class _EvHandle:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+    def done(self):
+        return self.ev.query()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    nmb = a.micro_batches or 2 * max(1, world)
+    max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
+    cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
+                       max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
+                       use_graphs=not a.no_graph, device="cpu" if a.cpu else "auto",
+                       backend="torch" if a.cpu else "auto", seed=0)
+    rank, world, rt, board, spec, cfg = attach_distributed(cfg)
+    if rank != 0:
+        stage_main(rt)
+        t = rt.barrier_times
+        elapsed = (t[-1] - t[-2]) if len(t) >= 2 else 0.0
+    else:
+        from distributed_llm_inference_amd.parallel.shm import ST_READY
+        board.set_state(0, ST_READY)
+        drv = Driver(rt, cfg, a)
+        drv.prefill()
+        ctx = a.prompt_len
+        for w in range(max(1, a.warmup)):           # the first round also uploads the batch composition
+            drv.decode_round(first=(w == 0), ctx=ctx)
+            ctx += 1
+        drv.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            drv.decode_round(first=False, ctx=ctx, record=True)
+            ctx += 1
+        drv.barrier()
+        elapsed = rt.barrier_times[-1] - rt.barrier_times[-2]
+        lat = drv.latencies_ms()
+        rt.execute(control(KIND_SHUTDOWN))
+        if rt.links.next_ctrl is not None:
+            pass
+    # MAX over ranks
+    if world > 1:
+        import torch.distributed as dist
+        dev = rt.device if rt.on_gpu else "cpu"
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        global_batch = cfg.num_micro_batches * cfg.max_batch
+        tokens = global_batch * a.steps
+        value = tokens / elapsed
+        base = baseline_for(a.model)
+        p50 = lat[len(lat) // 2] if lat else elapsed / a.steps * 1e3
+        plans = None
+        try:
+            from distributed_llm_inference_amd.parallel.launcher import plans_for
+            plans = [p.describe() for p in plans_for(cfg, spec)]
+        except Exception:
+            pass
+        print(json.dumps({
+            "metric": "output tokens/sec (whole node), Llama-3-8B layer-split PP=N",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": (round(value / base, 1) if base else None), "dtype": "fp32" if a.cpu else "bf16",
+            "data": "synthetic prompts (random token ids), random-init weights",
+            "p50_token_latency_ms": round(p50, 4),
+            "config": {"model": spec.name, "global_batch": global_batch, "seq_len": a.prompt_len,
+                       "parallelism": f"pp{world}", "micro_batches": cfg.num_micro_batches,
+                       "micro_batch_size": cfg.max_batch, "layer_ranges": plans,
+                       "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": cfg.use_graphs,
+                       "backend": rt.ex.backend}}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    rt.links.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -353,18 +353,19 @@ class GpuStage:
 
     def _capture(self, st: _MicroBatchState):
         # Warm up on a side stream (first-use initialisation must not happen under capture), then
-        # capture. The captured step advances ctx/steps, so save and restore them around both.
-        saved = (st.ctx.clone(), st.steps.clone())
+        # capture. The captured step advances ctx/steps (and, on a single-stage pipeline, feeds its
+        # tokens back into ids), so save and restore them around both.
+        saved = (st.ctx.clone(), st.steps.clone(), st.ids.clone())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
             self._decode_body(st)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1])
+        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._decode_body(st)
-        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1])
+        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
         st.graph = g
 
     # ---- introspection ----------------------------------------------------------------------

@@ -27,7 +27,7 @@ from typing import Callable, Dict, List, Optional
 
 import torch
 
-from ..runtime.batch import KIND_PING, KIND_RELEASE, KIND_SHUTDOWN, KIND_STEP, StepBatch
+from ..runtime.batch import KIND_BARRIER, KIND_PING, KIND_RELEASE, KIND_SHUTDOWN, KIND_STEP, StepBatch
 from .transport import Handle, PipelineLinks
 
 
@@ -79,6 +79,7 @@ class StageRuntime:
         self._eager_in: Optional[torch.Tensor] = None
         self._local_fb: Dict[int, torch.Tensor] = {}   # single-stage pipeline: last tokens per micro-batch
         self.steps = 0
+        self.barrier_times: List[float] = []
 
     # ---- helpers ---------------------------------------------------------------------------
     def _graph_decode(self, desc: StepBatch) -> bool:
@@ -113,6 +114,8 @@ class StageRuntime:
                 self.ex.release(desc.slots)
             if L.next_ctrl is not None:
                 L.next_ctrl.put(desc.to_bytes())
+            if desc.kind == KIND_BARRIER:
+                self.barrier()
             return None
         t_start = time.perf_counter_ns()
         self.fault.tick()
@@ -130,7 +133,13 @@ class StageRuntime:
                 if fb_wait is not None:
                     fb_wait.wait()
                 if graph:
-                    x = None                       # tokens are already in the graph's static input
+                    # tokens are already in the graph's static input — except right after an eager
+                    # step of a single-stage pipeline, whose tokens are still in a loose tensor
+                    x = None
+                    if L.num_stages == 1 and not desc.replay:
+                        prev = self._local_fb.get(mb)
+                        if prev is not None and prev.numel() == B:
+                            x = prev
                 elif L.num_stages == 1:
                     x = self._local_fb[mb]
                 else:
@@ -176,6 +185,21 @@ class StageRuntime:
             self.tracer.span(f"stage{self.stage}", "step", t_start, time.perf_counter_ns(),
                              {"mb": mb, "tokens": T, "decode": desc.is_decode})
         return result
+
+    def barrier(self):
+        """Finish everything this stage has enqueued, then meet the other stages. Records the
+        host time right after the barrier (used to bracket timed benchmark regions)."""
+        self.drain()
+        if self.links.num_stages > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                if self.on_gpu and dist.get_backend() == "nccl":
+                    dist.barrier(device_ids=[torch.device(self.device).index or 0])
+                else:
+                    dist.barrier()
+        if self.on_gpu:
+            torch.cuda.synchronize(self.device)
+        self.barrier_times.append(time.perf_counter())
 
     def drain(self):
         for h in self._send_pending.values():

@@ -25,6 +25,7 @@ KIND_STEP = 1        # run a forward step
 KIND_RELEASE = 2     # sequences finished: forget their slots
 KIND_SHUTDOWN = 3    # stop the stage loop
 KIND_PING = 4        # liveness probe, forwarded down the pipe and acknowledged by the last stage
+KIND_BARRIER = 5     # drain all outstanding work, then meet every other stage at a barrier
 
 _MAGIC = 0x444C4941  # "DLIA"
 
