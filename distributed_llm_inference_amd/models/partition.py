@@ -123,3 +123,18 @@ def make_plans(spec: ModelSpec, num_stages: int, mode: str = "balanced",
     return [StagePlan(stage=s, num_stages=num_stages, layer_start=a, layer_end=b,
                       has_embed=(s == 0), has_head=(s == num_stages - 1))
             for s, (a, b) in enumerate(bounds)]
+
+
+def make_worker_plans(spec: ModelSpec, num_workers: int, mode: str = "even",
+                      ranges: Optional[Sequence[Tuple[int, int]]] = None):
+    """The reference's topology: an orchestrator that owns embedding + final norm + lm_head and
+    `num_workers` workers that own only decoder layers (orchestration.py:45-47; Worker1.py:68-70).
+    Returns (edge_plan, worker_plans). With mode="even", 22 layers / 2 workers gives the
+    reference's [0,11) and [11,22)."""
+    if mode == "balanced":
+        mode = "even"          # nothing but layers on the workers: balanced == even
+    plans = make_plans(spec, num_workers, mode=mode, ranges=ranges)
+    workers = [StagePlan(stage=p.stage, num_stages=num_workers, layer_start=p.layer_start,
+                         layer_end=p.layer_end, has_embed=False, has_head=False) for p in plans]
+    edge = StagePlan(stage=-1, num_stages=num_workers, layer_start=0, layer_end=0, has_embed=True, has_head=True)
+    return edge, workers

@@ -16,6 +16,7 @@ import json
 import mmap
 import os
 import struct
+import warnings
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
@@ -71,7 +72,9 @@ class SafetensorsFile:
         if numel == 0:
             return torch.empty(shape, dtype=dt)
         buf = memoryview(self._mm)[self._data_start + b:self._data_start + en]
-        t = torch.frombuffer(buf, dtype=dt, count=numel)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)      # read-only mmap: callers copy/cast, never write
+            t = torch.frombuffer(buf, dtype=dt, count=numel)
         return t.reshape(shape)
 
     def close(self):

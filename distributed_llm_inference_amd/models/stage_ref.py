@@ -58,6 +58,20 @@ class RefStage:
         for s in slots:
             self.cache.pop(s, None)
 
+    # -- head / tail alone (the HTTP-compat orchestrator owns only these, as the reference's
+    #    orchestrator does: orchestration.py:45-47) ---------------------------------------
+    @torch.no_grad()
+    def embed_tokens(self, ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        h = self.w.embed[ids.long()]
+        if self.spec.is_gpt2:
+            h = h + self.w.pos_embed[positions.long()]
+        return h.to(self.dtype)
+
+    @torch.no_grad()
+    def head_logits(self, h_rows: torch.Tensor) -> torch.Tensor:
+        hn = self._norm(h_rows.to(self.dtype), self.w.final_norm_w, self.w.final_norm_b)
+        return R.gemm(hn, self.w.lm_head).float()
+
     # -- forward --------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, batch: StepBatch, x: torch.Tensor) -> torch.Tensor:

@@ -98,17 +98,61 @@ class Edge:
 class LoopbackEdge(Edge):
     def __init__(self):
         self.q: "queue.Queue[torch.Tensor]" = queue.Queue()
+        self._order_lock = threading.Lock()
+        self._next_ticket = 0
+        self._served = 0
 
     def send(self, t):
         self.q.put(t.detach().clone())
         return Handle()
 
     def recv(self, buf, timeout: float = 60.0):
-        t = self.q.get(timeout=timeout)
-        if t.numel() != buf.numel():
-            raise RuntimeError(f"loopback edge: expected {buf.numel()} elements, got {t.numel()}")
-        buf.copy_(t.reshape(buf.shape).to(buf.dtype))
-        return Handle()
+        return _LoopbackRecv(self, buf, timeout)
+
+
+class _LoopbackRecv(Handle):
+    """Receives are matched in posting order, like a real in-order transport: a handle may only
+    take from the queue once every earlier receive on the edge has taken its message."""
+
+    def __init__(self, edge: "LoopbackEdge", buf: torch.Tensor, timeout: float):
+        self.edge, self.buf, self.timeout = edge, buf, timeout
+        self._done = False
+        with edge._order_lock:
+            self.ticket = edge._next_ticket
+            edge._next_ticket += 1
+
+    def _take(self, block: bool) -> bool:
+        e = self.edge
+        with e._order_lock:
+            if self._done:
+                return True
+            if e._served != self.ticket:
+                return False
+            try:
+                t = e.q.get(block=False)
+            except queue.Empty:
+                if not block:
+                    return False
+                t = None
+            if t is None:
+                return False
+            if t.numel() != self.buf.numel():
+                raise RuntimeError(f"loopback edge: expected {self.buf.numel()} elements, got {t.numel()}")
+            self.buf.copy_(t.reshape(self.buf.shape).to(self.buf.dtype))
+            e._served += 1
+            self._done = True
+            return True
+
+    def done(self) -> bool:
+        return self._take(block=False)
+
+    def wait(self):
+        import time as _t
+        t0 = _t.monotonic()
+        while not self._take(block=False):
+            if _t.monotonic() - t0 > self.timeout:
+                raise TimeoutError("loopback edge: no message")
+            _t.sleep(0.0002)
 
 
 class TorchDistEdge(Edge):

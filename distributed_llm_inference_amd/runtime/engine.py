@@ -278,20 +278,15 @@ class Engine:
         if now - getattr(self, "_last_check", 0.0) < 0.25:
             return
         self._last_check = now
-        import os
+        from ..utils.procs import pid_alive
         for s in range(1, self.links.num_stages):
             st = self.board.read(s)
             dead = False
             if st["state"] == "error":
                 dead = True
                 why = f"stage {s} failed: {st['error']}"
-            elif st["state"] in ("ready", "starting") and st["pid"] > 0:
-                try:
-                    os.kill(st["pid"], 0)
-                except ProcessLookupError:
-                    dead, why = True, f"stage {s} (pid {st['pid']}) is gone"
-                except PermissionError:
-                    pass
+            elif st["state"] in ("ready", "starting") and st["pid"] > 0 and not pid_alive(st["pid"]):
+                dead, why = True, f"stage {s} (pid {st['pid']}) is gone"
             if not dead and any(mb.inflight for mb in self.mbs):
                 oldest = min(r.t_submit for mb in self.mbs for r in mb.inflight)
                 if now - oldest > self.cfg.hop_timeout_s * self.links.num_stages:
@@ -334,7 +329,7 @@ class Engine:
             waiting_fits = bool(self.waiting) and (mb.free_rows() + mb.dead_rows() > 0)
             if not live or waiting_fits or mb.dead_rows() * 2 >= max(1, len(live) + mb.dead_rows()):
                 mb.state = "draining"
-            elif len(mb.inflight) < self.cfg.max_inflight_steps and self._budget_left(mb):
+            elif len(mb.inflight) < self.cfg.max_inflight_steps and self._budget_left(mb) and self._fb_ready(mb):
                 self._submit_decode(mb, replay=True)
                 return True
 
@@ -368,6 +363,13 @@ class Engine:
                 mb.state = "draining"
             return True
         return progressed
+
+    def _fb_ready(self, mb: _MicroBatch) -> bool:
+        """On the GPU the next step waits for the fed-back tokens on the stream; on CPU transports
+        that wait would block this thread (and its watchdog), so only submit once they are in."""
+        if self.on_gpu or self.links.num_stages == 1 or mb.last_fb is None:
+            return True
+        return mb.last_fb.done()
 
     def _budget_left(self, mb: _MicroBatch) -> bool:
         """Is there a row that still needs tokens beyond what is already in flight?"""

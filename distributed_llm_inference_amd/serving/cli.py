@@ -1,0 +1,112 @@
+"""Command line: `python -m distributed_llm_inference_amd <command>`.
+
+    serve     orchestrator API over a pipeline of N stages (or over HTTP workers)
+    worker    one reference-compatible HTTP layer worker (/process, /health)
+    chat      interactive client (the reference's Test.py)
+    generate  one prompt through a local in-process engine
+    bench     the headline decode benchmark (same as bench.py)
+    plan      print the layer partition for a model / stage count
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import sys
+
+from ..config import EngineConfig
+
+
+def _add_engine_args(ap):
+    ap.add_argument("--config", help="YAML file with EngineConfig fields")
+    ap.add_argument("--model")
+    ap.add_argument("--pp-size", type=int)
+    ap.add_argument("--partition", choices=["balanced", "even", "explicit"])
+    ap.add_argument("--layer-ranges", help='explicit ranges, e.g. "0-11,11-22"')
+    ap.add_argument("--backend", choices=["auto", "hip", "torch"])
+    ap.add_argument("--device", choices=["auto", "cuda", "cpu"])
+    ap.add_argument("--transport", choices=["auto", "rccl", "gloo", "loopback", "http"])
+    ap.add_argument("--max-batch", type=int)
+    ap.add_argument("--num-micro-batches", type=int)
+    ap.add_argument("--max-seq-len", type=int)
+    ap.add_argument("--prefill-chunk", type=int)
+    ap.add_argument("--kv-blocks", type=int)
+    ap.add_argument("--max-tokens-cap", type=int)
+    ap.add_argument("--host")
+    ap.add_argument("--port", type=int)
+    ap.add_argument("--worker-urls", help="comma-separated worker URLs (HTTP relay mode)")
+    ap.add_argument("--seed", type=int)
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--debug-top5", action="store_true")
+    ap.add_argument("--fault-inject")
+
+
+def config_from_args(a) -> EngineConfig:
+    base = EngineConfig.from_yaml(a.config).to_dict() if getattr(a, "config", None) else {}
+    base = EngineConfig.from_env(EngineConfig.from_dict(base)).to_dict()
+    for k in ("model", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
+              "max_seq_len", "prefill_chunk", "kv_blocks", "max_tokens_cap", "host", "port", "seed", "fault_inject"):
+        v = getattr(a, k, None)
+        if v is not None:
+            base[k] = v
+    if getattr(a, "layer_ranges", None):
+        base["layer_ranges"] = [tuple(int(x) for x in p.split("-")) for p in a.layer_ranges.split(",")]
+    if getattr(a, "worker_urls", None):
+        base["worker_urls"] = [u for u in a.worker_urls.split(",") if u]
+    if getattr(a, "no_graphs", False):
+        base["use_graphs"] = False
+    if getattr(a, "debug_top5", False):
+        base["debug_top5"] = True
+    if getattr(a, "pp_size", None) is not None and getattr(a, "num_micro_batches", None) is None:
+        base["num_micro_batches"] = 0
+    return EngineConfig.from_dict(base)
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="distributed_llm_inference_amd", description=__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    p = sub.add_parser("serve"); _add_engine_args(p)
+    p = sub.add_parser("worker"); _add_engine_args(p)
+    p.add_argument("--index", type=int, required=True, help="0-based worker index")
+    p.add_argument("--num-workers", type=int, default=2)
+    p = sub.add_parser("chat"); p.add_argument("url", nargs="?")
+    p = sub.add_parser("generate"); _add_engine_args(p)
+    p.add_argument("prompt"); p.add_argument("--max-tokens", type=int, default=20)
+    p.add_argument("--temperature", type=float, default=None)
+    p = sub.add_parser("plan"); _add_engine_args(p)
+    p = sub.add_parser("bench"); p.add_argument("rest", nargs=argparse.REMAINDER)
+    a = ap.parse_args(argv)
+
+    if a.cmd == "serve":
+        from .orchestrator import serve
+        serve(config_from_args(a))
+    elif a.cmd == "worker":
+        from .worker import serve_worker
+        cfg = config_from_args(a)
+        serve_worker(cfg, a.index, a.num_workers, port=a.port)
+    elif a.cmd == "chat":
+        from .client import main as client_main
+        return client_main([a.url] if a.url else [])
+    elif a.cmd == "generate":
+        from ..parallel.launcher import make_pipeline
+        cfg = config_from_args(a)
+        pipe = make_pipeline(cfg)
+        try:
+            print(json.dumps(pipe.engine.generate_text(a.prompt, a.max_tokens, a.temperature), indent=2))
+        finally:
+            pipe.close()
+    elif a.cmd == "plan":
+        from ..parallel.launcher import plans_for, resolve_spec
+        cfg = config_from_args(a)
+        spec = resolve_spec(cfg)
+        for pl in plans_for(cfg, spec):
+            extra = [x for x, on in (("embedding", pl.has_embed), ("final norm + lm_head + sampler", pl.has_head)) if on]
+            print(f"stage {pl.stage}: layers [{pl.layer_start}, {pl.layer_end})" + (f" + {', '.join(extra)}" if extra else ""))
+    elif a.cmd == "bench":
+        import os
+        import runpy
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        sys.argv = ["bench.py"] + a.rest
+        runpy.run_path(os.path.join(root, "bench.py"), run_name="__main__")
+    return 0

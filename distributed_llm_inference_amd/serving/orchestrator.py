@@ -1,0 +1,286 @@
+"""Orchestrator HTTP API with the reference's contract (orchestration.py:230-356):
+
+    GET  /          HTML status page listing the workers / stages
+    GET  /health    {"status":"healthy","role":"orchestrator","model":...,"version":...}
+    GET  /workers   {"worker_1":"online"|"error"|"offline"|"not_configured", ...}
+    POST /generate  {"prompt": str, "max_tokens": int = 20, "temperature": float = 0.7}
+                    -> 200 {"prompt","response","status":"success","time_taken":"N.NNs",
+                            "tokens_generated":int,"tokens_per_sec":"N.NN"}
+                       400 {"error":"No prompt provided"}; 500 {"error":"Orchestrator not initialized"};
+                       200 {"error":"Error: ...","status":"failed"} on a runtime failure
+    GET  /metrics   Prometheus text (addition)
+
+Two backends sit behind the same routes: `EngineBackend` (the pipeline engine: stages over
+RCCL / gloo / loopback, continuous batching) and `HttpRelayBackend` (the reference's topology —
+embed / norm / lm_head / sampling here, layer workers behind `/process` URLs — kept for plumbing
+parity). Handlers only enqueue and wait; all serving state lives in the engine's scheduler thread.
+"""
+from __future__ import annotations
+
+import itertools
+import time
+from typing import Dict, List, Optional
+
+import torch
+
+from ..config import EngineConfig
+from ..runtime.sampler import sample_token, top_candidates
+from ..runtime.tokenizer import build_prompt
+
+VERSION = "dlia-mi355x-0.1"
+_HEADERS = {"ngrok-skip-browser-warning": "true", "Content-Type": "application/json"}   # orchestration.py:91-94
+
+
+class EngineBackend:
+    """/generate and /workers on top of a pipeline (`LocalPipeline` / `SpawnedPipeline`)."""
+
+    def __init__(self, pipeline):
+        self.pipe = pipeline
+        self.cfg: EngineConfig = pipeline.cfg
+        self.engine = pipeline.engine
+        self.model_name = pipeline.spec.name
+
+    def generate(self, prompt, max_new_tokens, temperature):
+        return self.engine.generate_text(prompt, max_new_tokens=max_new_tokens, temperature=temperature,
+                                         top_k=self.cfg.top_k, top_p=self.cfg.top_p)
+
+    def workers(self) -> Dict[str, str]:
+        """Stage s is reported as worker_{s+1}. online = ready with a fresh heartbeat; error = the
+        stage reported a failure; offline = its process is gone or silent; not_configured = it
+        never registered. Same vocabulary as orchestration.py:306-329."""
+        import os
+        from ..utils.procs import pid_alive
+        out = {}
+        board = self.pipe.board
+        limit_ms = self.cfg.health_timeout_s * 1000
+        for s in range(self.cfg.pp_size):
+            r = board.read(s)
+            if r["state"] == "unregistered":
+                st = "not_configured"
+            elif r["state"] == "error":
+                st = "error"
+            elif r["state"] == "stopped":
+                st = "offline"
+            else:
+                alive = True
+                if r["pid"] > 0 and r["pid"] != os.getpid():
+                    alive = pid_alive(r["pid"]) and r["age_ms"] <= limit_ms
+                st = "online" if alive and r["state"] == "ready" else ("offline" if not alive else "error")
+            out[f"worker_{s + 1}"] = st
+        return out
+
+    def worker_descriptions(self) -> List[str]:
+        board = self.pipe.board
+        return [f"stage {s}: layers {board.read(s)['layers']} ({board.read(s)['state']})" for s in range(self.cfg.pp_size)]
+
+    def metrics(self) -> str:
+        from .metrics import render
+        return render(self.engine.snapshot(), self.pipe.board, self.cfg.pp_size)
+
+    def close(self):
+        self.pipe.close()
+
+
+class HttpRelayBackend:
+    """The reference's own topology and loop (orchestration.py:69-228): this process owns the
+    tokenizer, embedding, final norm, lm_head and sampler; decoder layers live behind worker
+    URLs. With `incremental=True` (default) only the new tokens' rows are sent and the workers keep
+    a KV cache per request; with False the whole sequence is re-sent every step, as the reference does."""
+
+    def __init__(self, cfg: EngineConfig, incremental: bool = True):
+        import requests
+        from ..models.partition import make_worker_plans
+        from ..models.stage_ref import RefStage
+        from ..parallel.launcher import load_weights, make_tokenizer, resolve_spec
+        self.cfg = cfg
+        self.spec = resolve_spec(cfg)
+        self.model_name = self.spec.name
+        self.urls = [u.rstrip("/") for u in cfg.worker_urls]
+        edge, _ = make_worker_plans(self.spec, max(1, len(self.urls)), mode=cfg.partition, ranges=cfg.layer_ranges)
+        self.edge = RefStage(self.spec, edge, load_weights(cfg, self.spec, edge, "cpu", torch.float32),
+                             dtype=torch.float32, max_seq_len=cfg.max_seq_len)
+        self.tok = make_tokenizer(cfg, self.spec)
+        self.incremental = incremental
+        self.session = requests.Session()          # the reference opens a new connection per hop
+        self._ids = itertools.count(1)
+        self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0, "hops": 0}
+
+    def _hop(self, url: str, hidden: torch.Tensor, seq_id, ctx_len: int) -> torch.Tensor:
+        body = {"hidden_states": hidden.tolist()}
+        if self.incremental:
+            body["seq_id"], body["ctx_len"] = seq_id, ctx_len
+        r = self.session.post(f"{url}/process", json=body, headers=_HEADERS, timeout=self.cfg.hop_timeout_s)
+        self.stats["hops"] += 1
+        if r.status_code != 200:
+            raise RuntimeError(f"Worker at {url} failed: {r.text}")       # orchestration.py:121-122
+        return torch.tensor(r.json()["hidden_states"])
+
+    def generate(self, prompt, max_new_tokens, temperature):
+        start = time.time()
+        self.stats["requests"] += 1
+        if not self.urls or not all(self.urls):
+            return {"error": "Workers not configured!", "status": "failed"}        # orchestration.py:84-88
+        seq_id = f"r{next(self._ids)}"
+        try:
+            text = build_prompt(self.tok, prompt, self.cfg.system_prompt, self.cfg.chat_template)
+            ids = self.tok.encode(text)
+            self.stats["tokens_in"] += len(ids)
+            n = max(1, min(int(max_new_tokens), self.cfg.max_tokens_cap))
+            generated: List[int] = []
+            eos = getattr(self.tok, "eos_token_id", None)
+            cached = 0
+            debug = []
+            for step in range(n):
+                if self.incremental:
+                    new = ids[cached:]
+                    pos = torch.arange(cached, len(ids))
+                else:
+                    new, pos = ids, torch.arange(len(ids))
+                hidden = self.edge.embed_tokens(torch.tensor(new), pos).unsqueeze(0)      # [1, S, H]
+                for url in self.urls:
+                    hidden = self._hop(url, hidden, seq_id, cached)
+                cached = len(ids) if self.incremental else 0
+                logits = self.edge.head_logits(hidden[0, -1:, :])[0]
+                if self.cfg.debug_top5 and step < 3:                                      # orchestration.py:172-178
+                    debug.append(top_candidates(logits, temperature, self.cfg.top_k, self.cfg.top_p, 5))
+                nxt = sample_token(logits, temperature, self.cfg.top_k, self.cfg.top_p)
+                if eos is not None and nxt == eos:
+                    break
+                ids = ids + [nxt]
+                generated.append(nxt)
+            out_text = self.tok.decode(generated, skip_special_tokens=True)
+            elapsed = time.time() - start
+            tps = len(generated) / elapsed if elapsed > 0 else 0
+            self.stats["completed"] += 1
+            self.stats["tokens_out"] += len(generated)
+            res = {"prompt": prompt, "response": out_text, "status": "success", "time_taken": f"{elapsed:.2f}s",
+                   "tokens_generated": len(generated), "tokens_per_sec": f"{tps:.2f}"}
+            if debug:
+                res["top5_first_steps"] = debug
+            return res
+        except Exception as e:
+            self.stats["failed"] += 1
+            return {"error": f"Error: {e}", "status": "failed"}                          # orchestration.py:220-228
+        finally:
+            if self.incremental:
+                for url in self.urls:
+                    try:
+                        self.session.post(f"{url}/release", json={"seq_id": seq_id}, headers=_HEADERS, timeout=5)
+                    except Exception:
+                        pass
+
+    def workers(self) -> Dict[str, str]:
+        out = {}
+        for i, url in enumerate(self.urls or [""]):
+            key = f"worker_{i + 1}"
+            if not url:
+                out[key] = "not_configured"
+                continue
+            try:
+                r = self.session.get(f"{url}/health", headers=_HEADERS, timeout=self.cfg.health_timeout_s)
+                out[key] = "online" if r.status_code == 200 else "error"
+            except Exception:
+                out[key] = "offline"
+        return out
+
+    def worker_descriptions(self) -> List[str]:
+        return [f"Worker {i + 1}: {u or 'Not configured'}" for i, u in enumerate(self.urls)]
+
+    def metrics(self) -> str:
+        from .metrics import render
+        return render(dict(self.stats))
+
+    def close(self):
+        self.session.close()
+
+
+def create_app(backend):
+    """Flask app exposing the orchestrator routes over `backend` (None = not initialised)."""
+    from flask import Flask, Response, jsonify, request
+    app = Flask("dlia-orchestrator")
+    app.config["backend"] = backend
+
+    @app.after_request
+    def _cors(resp):                                                   # orchestration.py:232
+        resp.headers["Access-Control-Allow-Origin"] = "*"
+        resp.headers["Access-Control-Allow-Headers"] = "Content-Type, ngrok-skip-browser-warning"
+        resp.headers["Access-Control-Allow-Methods"] = "GET, POST, OPTIONS"
+        return resp
+
+    @app.route("/")
+    def home():
+        b = app.config["backend"]
+        rows = "".join(f"<p>{d}</p>" for d in (b.worker_descriptions() if b else ["not initialized"]))
+        model = b.model_name if b else "-"
+        return f"""<!DOCTYPE html><html><head><title>Distributed LLM API</title>
+<style>body{{font-family:Arial,sans-serif;max-width:900px;margin:50px auto;padding:30px;
+background:linear-gradient(135deg,#667eea 0%,#764ba2 100%);color:white}}
+.container{{background:rgba(255,255,255,0.1);padding:40px;border-radius:20px}}
+.status{{display:inline-block;background:#4CAF50;padding:8px 20px;border-radius:25px;font-weight:bold}}
+.section{{background:rgba(0,0,0,0.2);padding:20px;border-radius:10px;margin:20px 0}}</style></head>
+<body><div class="container"><h1>Distributed LLM API</h1>
+<h2>Status: <span class="status">{'ONLINE' if b else 'STARTING'}</span></h2>
+<div class="section"><h3>Model</h3><p>{model}</p><p>Engine {VERSION}: layer-split pipeline on MI355X,
+paged KV cache, temperature / top-k / top-p sampling, chat formatting.</p></div>
+<div class="section"><h3>Workers</h3>{rows}</div>
+<div class="section"><h3>Routes</h3><p>GET /health &middot; GET /workers &middot; POST /generate &middot; GET /metrics</p></div>
+</div></body></html>"""
+
+    @app.route("/health", methods=["GET"])
+    def health():
+        b = app.config["backend"]
+        return jsonify({"status": "healthy", "role": "orchestrator",
+                        "model": b.model_name if b else None, "version": VERSION})
+
+    @app.route("/workers", methods=["GET"])
+    def workers():
+        b = app.config["backend"]
+        if b is None:
+            return jsonify({"worker_1": "not_configured"})
+        return jsonify(b.workers())
+
+    @app.route("/generate", methods=["POST", "OPTIONS"])
+    def generate():
+        if request.method == "OPTIONS":
+            return "", 204
+        b = app.config["backend"]
+        if b is None:
+            return jsonify({"error": "Orchestrator not initialized"}), 500        # orchestration.py:335-336
+        data = request.get_json(silent=True) or {}
+        prompt = data.get("prompt", "")
+        max_tokens = data.get("max_tokens", b.cfg.default_max_tokens)
+        temperature = data.get("temperature", b.cfg.temperature)
+        if not prompt:
+            return jsonify({"error": "No prompt provided"}), 400                 # orchestration.py:343-344
+        try:
+            max_tokens = min(int(max_tokens), b.cfg.max_tokens_cap)              # orchestration.py:347 (cap 30 there)
+            temperature = float(temperature)
+        except (TypeError, ValueError):
+            return jsonify({"error": "max_tokens and temperature must be numbers"}), 400
+        return jsonify(b.generate(prompt, max_tokens, temperature))              # HTTP 200 even when status == failed
+
+    @app.route("/metrics", methods=["GET"])
+    def metrics():
+        b = app.config["backend"]
+        return Response(b.metrics() if b else "", mimetype="text/plain; version=0.0.4")
+
+    return app
+
+
+def serve(cfg: EngineConfig):
+    """Blocking: bring the pipeline (or the HTTP relay) up and serve the API on cfg.host:cfg.port."""
+    from ..utils.tracing import get_logger
+    log = get_logger()
+    if cfg.resolved_transport() == "http" or cfg.worker_urls:
+        backend = HttpRelayBackend(cfg)
+        log.info("orchestrator (HTTP relay) for %s; workers: %s", backend.model_name, cfg.worker_urls)
+    else:
+        from ..parallel.launcher import make_pipeline
+        backend = EngineBackend(make_pipeline(cfg))
+        log.info("orchestrator for %s: %d stage(s), backend %s, transport %s", backend.model_name, cfg.pp_size,
+                 cfg.resolved_backend(), cfg.resolved_transport())
+    app = create_app(backend)
+    try:
+        app.run(host=cfg.host, port=cfg.port, debug=False, threaded=True)
+    finally:
+        backend.close()

@@ -1,0 +1,228 @@
+"""API contract of the orchestrator and the HTTP worker (status codes and JSON schemas of the
+reference: orchestration.py:236-356, Worker1.py:185-245), the client library, the HTTP relay
+topology with real worker processes on localhost, and fault handling."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+from distributed_llm_inference_amd.config import EngineConfig
+from distributed_llm_inference_amd.parallel.launcher import LocalPipeline, make_pipeline
+from distributed_llm_inference_amd.runtime.sampler import SamplingParams
+from distributed_llm_inference_amd.serving.orchestrator import EngineBackend, HttpRelayBackend, create_app
+from distributed_llm_inference_amd.serving.worker import WorkerService, build_worker_service, create_worker_app
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cfg(**kw):
+    base = dict(model="tiny-llama-test", pp_size=1, max_batch=4, num_micro_batches=2, max_seq_len=160,
+                prefill_chunk=32, backend="torch", device="cpu", transport="loopback", seed=3)
+    base.update(kw)
+    return EngineConfig(**base)
+
+
+@pytest.fixture(scope="module")
+def backend():
+    b = EngineBackend(LocalPipeline(cfg(pp_size=2, partition="even")))
+    yield b
+    b.close()
+
+
+def test_orchestrator_routes(backend):
+    c = create_app(backend).test_client()
+    r = c.get("/health")
+    assert r.status_code == 200
+    assert set(r.get_json()) == {"status", "role", "model", "version"}
+    assert r.get_json()["status"] == "healthy" and r.get_json()["role"] == "orchestrator"
+    r = c.get("/workers")
+    assert r.get_json() == {"worker_1": "online", "worker_2": "online"}
+    r = c.get("/")
+    assert r.status_code == 200 and b"Distributed LLM API" in r.data and b"stage 1" in r.data
+    r = c.post("/generate", json={"prompt": "Hello", "max_tokens": 6})
+    d = r.get_json()
+    assert r.status_code == 200 and d["status"] == "success" and d["prompt"] == "Hello"
+    assert {"prompt", "response", "status", "time_taken", "tokens_generated", "tokens_per_sec"} <= set(d)
+    assert isinstance(d["time_taken"], str) and d["time_taken"].endswith("s")
+    assert isinstance(d["tokens_per_sec"], str) and isinstance(d["tokens_generated"], int) and d["tokens_generated"] <= 6
+    assert r.headers["Access-Control-Allow-Origin"] == "*"
+    assert c.post("/generate", json={"max_tokens": 3}).status_code == 400
+    assert c.post("/generate", json={"prompt": ""}).get_json() == {"error": "No prompt provided"}
+    # logical failure -> HTTP 200 + error envelope (orchestration.py:220-228,356)
+    r = c.post("/generate", json={"prompt": "x" * 4000})
+    assert r.status_code == 200 and r.get_json()["status"] == "failed" and r.get_json()["error"].startswith("Error: ")
+    # temperature 0 is greedy here (it is a crash in the reference)
+    a = c.post("/generate", json={"prompt": "Hi", "max_tokens": 5, "temperature": 0}).get_json()
+    b = c.post("/generate", json={"prompt": "Hi", "max_tokens": 5, "temperature": 0}).get_json()
+    assert a["status"] == "success" and a["response"] == b["response"]
+    m = c.get("/metrics").data.decode()
+    assert "dlia_tokens_generated_total" in m and 'dlia_stage_up{stage="1"' in m
+
+
+def test_orchestrator_not_initialised():
+    c = create_app(None).test_client()
+    r = c.post("/generate", json={"prompt": "x"})
+    assert r.status_code == 500 and r.get_json() == {"error": "Orchestrator not initialized"}
+    assert c.get("/workers").get_json() == {"worker_1": "not_configured"}
+
+
+def test_token_cap_is_configurable(backend):
+    c = create_app(backend).test_client()
+    old = backend.cfg.max_tokens_cap
+    backend.cfg.max_tokens_cap = 3                     # the reference hard-codes 30 (orchestration.py:347)
+    try:
+        d = c.post("/generate", json={"prompt": "count", "max_tokens": 50, "temperature": 0}).get_json()
+        assert d["tokens_generated"] <= 3
+    finally:
+        backend.cfg.max_tokens_cap = old
+
+
+def test_worker_routes_stateless_and_incremental():
+    svc = build_worker_service(cfg(), 0, 2)
+    c = create_worker_app(svc).test_client()
+    h = c.get("/health").get_json()
+    assert h == {"status": "healthy", "role": "worker_1", "layers": "0-2", "model": "tiny-llama-test"}
+    assert b"Worker 1" in c.get("/").data
+    assert c.post("/process", json={}).status_code == 400
+    assert c.post("/process", json={"hidden_states": []}).get_json() == {"error": "No hidden states provided"}
+    r = c.post("/process", json={"hidden_states": [[[0.0] * 7]]})
+    assert r.status_code == 500 and "error" in r.get_json()
+    x = torch.randn(1, 6, 128)
+    full = c.post("/process", json={"hidden_states": x.tolist()}).get_json()
+    assert full["status"] == "success" and full["worker"] == "worker_1"
+    want = torch.tensor(full["hidden_states"])
+    assert want.shape == (1, 6, 128)
+    # stateless: the same request again gives the same answer (nothing was cached)
+    again = torch.tensor(c.post("/process", json={"hidden_states": x.tolist()}).get_json()["hidden_states"])
+    assert torch.allclose(again, want, atol=1e-6)
+    # incremental: 4 tokens, then 2 more with ctx_len=4 == the last two rows of the full pass
+    c.post("/process", json={"hidden_states": x[:, :4].tolist(), "seq_id": "a", "ctx_len": 0})
+    inc = c.post("/process", json={"hidden_states": x[:, 4:].tolist(), "seq_id": "a", "ctx_len": 4}).get_json()
+    assert torch.allclose(torch.tensor(inc["hidden_states"]), want[:, 4:], atol=1e-5)
+    assert c.post("/release", json={"seq_id": "a"}).get_json()["released"] == 1
+    assert create_worker_app(None).test_client().post("/process", json={"hidden_states": [[[1.0]]]}).status_code == 500
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _wait_http(url, timeout=90):
+    import requests
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        try:
+            if requests.get(url, timeout=1).status_code == 200:
+                return True
+        except Exception:
+            time.sleep(0.2)
+    return False
+
+
+@pytest.fixture(scope="module")
+def http_workers():
+    """Orchestrator + 2 CPU worker PROCESSES on localhost, GPT-2 architecture split across them."""
+    ports = [_free_port(), _free_port()]
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, "-m", "distributed_llm_inference_amd", "worker", "--model", "tiny-gpt2-test",
+                               "--index", str(i), "--num-workers", "2", "--port", str(p), "--host", "127.0.0.1",
+                               "--backend", "torch", "--device", "cpu", "--seed", "3", "--max-seq-len", "160"],
+                              env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+             for i, p in enumerate(ports)]
+    urls = [f"http://127.0.0.1:{p}" for p in ports]
+    ok = all(_wait_http(u + "/health") for u in urls)
+    yield urls, procs, ok
+    for p in procs:
+        p.terminate()
+    for p in procs:
+        p.wait(10)
+
+
+def test_http_relay_topology_matches_pipeline_engine(http_workers):
+    urls, procs, ok = http_workers
+    assert ok, "workers did not come up"
+    relay = HttpRelayBackend(cfg(model="tiny-gpt2-test", worker_urls=urls, transport="http"))
+    stateless = HttpRelayBackend(cfg(model="tiny-gpt2-test", worker_urls=urls, transport="http"), incremental=False)
+    eng = EngineBackend(LocalPipeline(cfg(model="tiny-gpt2-test")))
+    try:
+        assert relay.workers() == {"worker_1": "online", "worker_2": "online"}
+        a = relay.generate("Hello there", 8, 0.0)
+        b = stateless.generate("Hello there", 8, 0.0)          # whole sequence re-sent every step (the reference)
+        c = eng.generate("Hello there", 8, 0.0)
+        assert a["status"] == b["status"] == c["status"] == "success"
+        assert a["response"] == b["response"] == c["response"]
+        assert a["tokens_generated"] == c["tokens_generated"]
+        assert stateless.stats["hops"] == relay.stats["hops"]
+        # the acceptance client (the reference's Test.py) against a live server
+        from distributed_llm_inference_amd.serving.client import DistributedLLMClient
+        import threading
+        from werkzeug.serving import make_server
+        port = _free_port()
+        srv = make_server("127.0.0.1", port, create_app(relay), threaded=True)
+        t = threading.Thread(target=srv.serve_forever, daemon=True)
+        t.start()
+        try:
+            cl = DistributedLLMClient(f"http://127.0.0.1:{port}/", verbose=False)
+            assert cl.api_url == f"http://127.0.0.1:{port}" and cl.check_health() is True
+            assert cl.check_workers() == {"worker_1": "online", "worker_2": "online"}
+            d = cl.generate("Hello", max_tokens=5)
+            assert d and d["status"] == "success"
+            said = iter(["health", "workers", "", "Hi", "q"])
+            cl.interactive_chat(input_fn=lambda _: next(said), max_tokens=3)
+        finally:
+            srv.shutdown()
+    finally:
+        relay.close(); stateless.close(); eng.close()
+
+
+def test_http_relay_reports_dead_worker(http_workers):
+    urls, procs, ok = http_workers
+    assert ok
+    dead = f"http://127.0.0.1:{_free_port()}"
+    relay = HttpRelayBackend(cfg(model="tiny-gpt2-test", worker_urls=[urls[0], dead, ""], transport="http", hop_timeout_s=3))
+    try:
+        assert relay.workers() == {"worker_1": "online", "worker_2": "offline", "worker_3": "not_configured"}
+        out = relay.generate("Hello", 4, 0.7)
+        assert out == {"error": "Workers not configured!", "status": "failed"}
+        relay.urls = [urls[0], dead]
+        out = relay.generate("Hello", 4, 0.7)
+        assert out["status"] == "failed" and out["error"].startswith("Error: ")
+    finally:
+        relay.close()
+
+
+def test_stage_failure_fails_requests_and_shows_in_workers():
+    """Kill a stage process mid-generation: in-flight requests get the error envelope within the
+    timeout and /workers reports the stage offline (parity with orchestration.py:121-122,220-228)."""
+    pipe = make_pipeline(cfg(pp_size=2, partition="even", transport="gloo", fault_inject="stage1:exit@4",
+                             hop_timeout_s=5))
+    b = EngineBackend(pipe)
+    try:
+        t0 = time.time()
+        out = b.generate("Hello", 20, 0.0)
+        assert out["status"] == "failed" and out["error"].startswith("Error: ")
+        assert time.time() - t0 < 60
+        w = b.workers()
+        assert w["worker_1"] == "online" and w["worker_2"] == "offline"
+        again = b.generate("Hello", 4, 0.0)               # the engine stays failed, it does not hang
+        assert again["status"] == "failed"
+    finally:
+        b.close()
+
+
+def test_injected_exception_on_a_thread_stage_is_reported():
+    pipe = LocalPipeline(cfg(pp_size=2, partition="even", fault_inject="stage1:raise@2", hop_timeout_s=2))
+    try:
+        r = pipe.engine.submit([5, 6, 7], SamplingParams(temperature=0.0, max_new_tokens=10, stop_on_eos=False))
+        r.wait(60)
+        assert r.state == "failed"
+        assert pipe.board.read(1)["state"] == "error" and "injected fault" in pipe.board.read(1)["error"]
+    finally:
+        pipe.close()
