@@ -126,7 +126,15 @@ class GpuStage:
         self.qkv = z(MT, spec.qkv_size)
         self.attn = z(MT, spec.q_size)
         self.act = z(MT, I)
-        self.ws = z(16 * 64 * max(spec.qkv_size, 2 * I if spec.is_llama else I, H), dt=torch.float32)
+        # split-K partial workspace [S, M, N]: one buffer, reused by every GEMM of a step (each
+        # partial is consumed by the next kernel before the next GEMM writes)
+        need = 1
+        for (n_, k_, e_) in ((spec.qkv_size, H, 6), (H, spec.q_size, 6), (H, I, 6),
+                             (2 * I if spec.is_llama else I, H, 4 if spec.is_llama else 5),
+                             (packing.padded_n(V), H, 0)):
+            for m_ in range(1, 129):        # any token count up to 128 takes the weight-streaming path
+                need = max(need, int(self.K.gemm_config(m_, n_, k_, e_, True)[1]) * m_ * n_)
+        self.ws = z(need, dt=torch.float32)
         self.max_splits = 16
         self.attn_ws = z(int(self.K.attention_ws_floats(max_batch, 1, spec.num_heads, spec.num_kv_heads,
                                                         spec.head_dim, self.max_splits)), dt=torch.float32)
@@ -139,6 +147,8 @@ class GpuStage:
         self.md_q_start, self.md_ctx, self.md_slots = i32(max_batch + 1), i32(max_batch), i32(max_batch)
         self.md_rows, self.md_ids = i32(max_batch), i32(MT)
         self._mbs: Dict[int, _MicroBatchState] = {}
+        self._gemm_cfg: Dict[tuple, tuple] = {}
+        self._ones = torch.ones(H, device=dev, dtype=bf)
         self.scale = 1.0 / math.sqrt(spec.head_dim)
         self.graph_replays = 0
 
@@ -164,35 +174,90 @@ class GpuStage:
                 self.block_table[s].fill_(-1)
 
     # ---- the layer stack on T tokens ------------------------------------------------------
+    def _cfg(self, M: int, N: int, K: int, epi: int):
+        key = (M, N, K, epi)
+        c = self._gemm_cfg.get(key)
+        if c is None:
+            c = tuple(int(v) for v in self.K.gemm_config(M, N, K, epi, True))
+            self._gemm_cfg[key] = c
+        return c
+
     def _layers(self, T: int, B: int, tok_pos, tok_seq, q_start, ctx, slots, max_q: int, splits: int):
+        """Runs this stage's decoder layers on self.h[:T]. Returns the pending split-K partial
+        (splits, bias) of the last down projection that the caller still has to fold into h
+        (decode regime), or None when h is final."""
         K, s = self.K, self.spec
         h, xn, qkv, attn, act = self.h[:T], self.xn[:T], self.qkv[:T], self.attn[:T], self.act[:T]
         Hq, Hkv, D, H, I = s.num_heads, s.num_kv_heads, s.head_dim, s.hidden_size, s.intermediate_size
-        ws = self.ws if T <= 64 else None
         partial = self.attn_ws if splits > 1 else None
         llama = s.is_llama
+        nmode = 0 if llama else 1
+        if T > 128:
+            # prefill regime: tiled MFMA GEMMs with fused bias / residual / activation epilogues
+            for li, p in enumerate(self.layers):
+                kv = self.kv[li]
+                K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
+                K.gemm(qkv, xn, p["w_qkv"], p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
+                K.rope_kvwrite(qkv, None, 1, None, kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
+                               Hq, Hkv, D, llama)
+                K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
+                                  self.scale, splits)
+                K.gemm(h, attn, p["w_o"], p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
+                K.norm(xn, h, None, None, 1, None, p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
+                if llama:
+                    K.gemm(act, xn, p["w_gu"], None, None, None, 2 * I, 4, 1, 0)
+                    K.gemm(h, act, p["w_down"], None, h, None, H, 2, 1, 0)
+                else:
+                    K.gemm(act, xn, p["w_fc"], p["b_fc"], None, None, I, 5, 1, 0)
+                    K.gemm(h, act, p["w_down"], p["b_down"], h, None, H, 3, 1, 0)
+            return None
+        # decode regime: weight-streaming GEMMs write fp32 split-K partials which the NEXT kernel
+        # (norm / rope) sums while it reads them anyway — no reduce launches, no bf16 round trip
+        ws = self.ws
+        nq, sq = self._cfg(T, s.qkv_size, H, 6)
+        no, so = self._cfg(T, H, s.q_size, 6)
+        nd, sd = self._cfg(T, H, I, 6)
+        pend = None
         for li, p in enumerate(self.layers):
             kv = self.kv[li]
-            K.norm(xn, h, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, not llama)
-            K.gemm(qkv, xn, p["w_qkv"], p.get("b_qkv"), None, ws, s.qkv_size, 0 if llama else 1, 0)
-            K.rope_kvwrite(qkv, kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table, Hq, Hkv, D, llama)
+            if pend is None:
+                K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
+            else:
+                K.norm(xn, h, None, ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
+            K.gemm(qkv, xn, p["w_qkv"], None, None, ws, s.qkv_size, 6, sq, nq)
+            K.rope_kvwrite(qkv, ws, sq, p.get("b_qkv"), kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
+                           Hq, Hkv, D, llama)
             K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
                               self.scale, splits)
-            K.gemm(h, attn, p["w_o"], p.get("b_o"), h, ws, H, 2 if llama else 3, 0)
-            K.norm(xn, h, None, p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, not llama)
+            K.gemm(h, attn, p["w_o"], None, None, ws, H, 6, so, no)
+            K.norm(xn, h, None, ws, so, p.get("b_o"), p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
             if llama:
-                K.gemm(act, xn, p["w_gu"], None, None, ws, 2 * I, 4, 0)
-                K.gemm(h, act, p["w_down"], None, h, ws, H, 2, 0)
+                K.gemm(act, xn, p["w_gu"], None, None, ws, 2 * I, 4, 0, 0)
             else:
-                K.gemm(act, xn, p["w_fc"], p["b_fc"], None, ws, I, 5, 0)
-                K.gemm(h, act, p["w_down"], p["b_down"], h, ws, H, 3, 0)
+                K.gemm(act, xn, p["w_fc"], p["b_fc"], None, ws, I, 5, 0, 0)
+            K.gemm(h, act, p["w_down"], None, None, ws, H, 6, sd, nd)
+            pend = (sd, p.get("b_down"))
+        return pend
 
-    def _head(self, rows_idx: torch.Tensor, R: int):
-        """Final norm on the selected rows of self.h, then lm_head -> self.logits[:R]."""
+    def _fold(self, T: int, pend):
+        """h[:T] += pending partials (stage output that is sent on rather than normalised here)."""
+        if pend is not None:
+            self.K.norm(self.xn[:T], self.h[:T], None, self.ws, pend[0], pend[1], self._ones, None, None,
+                        self.spec.norm_eps, 2)
+
+    def _head(self, rows_idx: torch.Tensor, R: int, T: int, pend):
+        """Final norm on the selected rows of self.h (folding the pending partials of those rows
+        first), then lm_head -> self.logits[:R]."""
         s, K = self.spec, self.K
         hx = self.head_x[:R]
-        K.norm(hx, self.h, None, self.final_norm_w, self.final_norm_b, rows_idx[:R], s.norm_eps, not s.is_llama)
-        K.gemm(self.logits[:R], hx, self.lm_head, None, None, self.ws, self.vocab_pad, 0, 0)
+        nmode = 0 if s.is_llama else 1
+        if pend is None:
+            K.norm(hx, self.h[:T], None, None, 1, None, self.final_norm_w, self.final_norm_b, rows_idx[:R],
+                   s.norm_eps, nmode)
+        else:
+            K.norm(hx, self.h[:T], None, self.ws, pend[0], pend[1], self.final_norm_w, self.final_norm_b,
+                   rows_idx[:R], s.norm_eps, nmode)
+        K.gemm(self.logits[:R], hx, self.lm_head, None, None, self.ws, self.vocab_pad, 0, 0, 0)
         return self.logits[:R]
 
     # ---- generic (eager) forward: prefill chunks, and decode when graphs are off ---------
@@ -227,15 +292,18 @@ class GpuStage:
                 raise ValueError(f"expected hidden [{T},{s.hidden_size}], got {tuple(x.shape)}")
             self.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16))
         max_q = max(batch.q_lens) if batch.q_lens else 1
-        self._layers(T, B, self.md_tok_pos[:T], self.md_tok_seq[:T], self.md_q_start[:B + 1], self.md_ctx[:B],
-                     self.md_slots[:B], max_q, 1)
+        pend = self._layers(T, B, self.md_tok_pos[:T], self.md_tok_seq[:T], self.md_q_start[:B + 1], self.md_ctx[:B],
+                            self.md_slots[:B], max_q, 1)
         if not self.plan.has_head:
+            self._fold(T, pend)
             return self.h[:T]
         R = len(rows)
         if R == 0:
             return self.logits[:0, :s.vocab_size]
+        if R > self.max_batch:
+            raise ValueError(f"{R} sampled rows exceed max_batch {self.max_batch}")
         up(self.md_rows, rows)
-        return self._head(self.md_rows, R)[:, :s.vocab_size]
+        return self._head(self.md_rows, R, T, pend)[:, :s.vocab_size]
 
     @torch.no_grad()
     def sample(self, batch: StepBatch, logits: torch.Tensor) -> torch.Tensor:
@@ -278,15 +346,16 @@ class GpuStage:
             K.embed(self.h[:B], st.ids, st.ctx, self.embed, self.pos_embed)
         else:
             self.h[:B].copy_(st.hidden_in)
-        self._layers(B, B, st.ctx, st.slots, self._arange[:B + 1], st.ctx, st.slots, 1, st.splits)
+        pend = self._layers(B, B, st.ctx, st.slots, self._arange[:B + 1], st.ctx, st.slots, 1, st.splits)
         if self.plan.has_head:
-            self._head(self._arange, B)
+            self._head(self._arange, B, B, pend)
             K.sample(st.tokens, self.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
                      self.spec.vocab_size, None, None)
             K.advance(st.steps, 1)
             if self.plan.has_embed:
                 st.ids.copy_(st.tokens)      # single-stage pipeline: the feedback hop is local
         else:
+            self._fold(B, pend)
             st.hidden_out.copy_(self.h[:B])
         K.advance(st.ctx, 1)
 
@@ -342,12 +411,14 @@ class GpuStage:
         return st.ids if self.plan.has_embed else st.hidden_in
 
     def _pick_splits(self, B: int, max_ctx: int) -> int:
-        """Split-KV factor: enough waves to fill the chip when sequences x kv-heads is small."""
-        items = B * self.spec.num_kv_heads
-        if max_ctx < 256 or items >= 2048:
+        """Inter-workgroup split-KV factor. A (sequence, kv head) item already spreads its KV
+        blocks over the 4 waves of its workgroup; more splits are only worth their merge kernel
+        when there are too few items to fill the chip and the context is long."""
+        waves = B * self.spec.num_kv_heads * 4
+        if max_ctx < 1024 or waves >= 2048:
             return 1
         s = 1
-        while items * s < 2048 and s < self.max_splits and (max_ctx // (s * 2)) >= 64:
+        while waves * s < 2048 and s < self.max_splits and (max_ctx // (s * 2)) >= 256:
             s *= 2
         return s
 

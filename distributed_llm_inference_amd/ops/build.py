@@ -17,6 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
+HIP_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-fno-math-errno", "-fno-gpu-rdc",
+             "-Wno-unused-result"]
+# kernels with hand-counted vmcnt waits: {source: kernel-name regex}; their ISA is linted after compiling
+LINTED = {"gemm_skinny.hip": "gemm_skinny_kernel"}
 
 
 def _run(cmd):
@@ -33,6 +37,18 @@ def _stale(src, obj, extra_deps=()):
     return any(os.path.getmtime(d) > t for d in (src, *extra_deps))
 
 
+def _lint(hipcc, src, regex):
+    """Compile `src` to ISA text and make sure no in-flight load destination is read early."""
+    from .isa_lint import lint_asm
+    asm = os.path.join(OBJ, os.path.basename(src) + ".s")
+    _run([hipcc, *HIP_FLAGS, "-S", "--cuda-device-only", src, "-o", asm])
+    with open(asm) as f:
+        bad = lint_asm(f.read(), regex)
+    if bad:
+        raise RuntimeError(f"{src}: {len(bad)} instruction(s) read a register whose load is still in flight, "
+                           f"first: {bad[0][0]}: {bad[0][1]}")
+
+
 def build(verbose: bool = True, force: bool = False) -> str:
     import torch
     from torch.utils import cpp_extension as ce
@@ -43,12 +59,14 @@ def build(verbose: bool = True, force: bool = False) -> str:
     hip_srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     jobs = []
     objs = []
+    lint = []
     for f in hip_srcs:
         src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f + ".o")
         objs.append(obj)
         if force or _stale(src, obj, headers):
-            jobs.append([hipcc, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-fno-math-errno",
-                         "-fno-gpu-rdc", "-Wno-unused-result", "-c", src, "-o", obj])
+            jobs.append([hipcc, *HIP_FLAGS, "-c", src, "-o", obj])
+            if f in LINTED:
+                lint.append((src, LINTED[f]))
     tinc = []
     for p in ce.include_paths("cuda"):
         tinc += ["-isystem", p]
@@ -63,6 +81,8 @@ def build(verbose: bool = True, force: bool = False) -> str:
             print(f"[dlia.build] compiling {len(jobs)} translation unit(s) for {ARCH}", flush=True)
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
+        for src, regex in lint:
+            _lint(hipcc, src, regex)
     out = os.path.join(HERE, "_C.so")
     if jobs or not os.path.exists(out):
         tlib = os.path.join(os.path.dirname(torch.__file__), "lib")

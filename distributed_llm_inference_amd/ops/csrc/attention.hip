@@ -1,7 +1,9 @@
 // Causal GQA attention over the paged, fragment-ordered KV cache (kv_layout.h).
 //
 // One kernel serves chunked prefill and single-token decode: a work item is
-// (sequence b, kv head, query tile, kv split) and is owned by ONE wave — no LDS, no barriers.
+// (sequence b, kv head, query tile, kv split) and is owned by one 4-wave workgroup whose waves
+// interleave the item's KV blocks and merge their (m, l, O) through LDS once at the end — the
+// main loop has no LDS traffic and no barriers.
 // The wave's MFMA columns are "query columns" c = (position-in-tile, head-in-GQA-group): all
 // query heads that share a kv head ride in the same MFMA, so K/V are read once per group.
 //
@@ -46,12 +48,13 @@ template <int D, int NT>
 __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
   constexpr int KS = D / 32;      // MFMA k-steps over the head dim (QK^T)
   constexpr int DT = D / 16;      // 16-row tiles of the head dim (PV)
-  constexpr int NC = NT * 16;     // query columns per wave
+  constexpr int NC = NT * 16;     // query columns per workgroup
+  constexpr bool PREFETCH = NT == 1;   // decode: next block's K/V in flight while this one is used
+  // LDS: per wave its (m, l) per lane and its O accumulators, merged by the 4 waves at the end
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, l15 = lane & 15, quad = lane >> 4;
   const int wave = threadIdx.x >> 6;
-  long item = (long)blockIdx.x * 4 + wave;
-  const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
-  if (item >= nitems) return;
+  long item = blockIdx.x;
   const int split = (int)(item % p.splits); item /= p.splits;
   const int qtile = (int)(item % p.qtiles); item /= p.qtiles;
   const int kvh = (int)(item % p.Hkv);
@@ -66,11 +69,11 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
   const bool srow_ok = srow >= 0 && srow < p.table_rows;
   srow = srow_ok ? srow : 0;
   const int qp0 = qtile * QT;
-  const bool tile_live = qp0 < q_len;             // wave-uniform
+  const bool tile_live = qp0 < q_len;             // workgroup-uniform
 
   // column bookkeeping: lane's column within tile nt is c = nt*16 + l15
   int col_qpos[NT];       // position within the chunk, or -1 when the column is padding
-  long col_row[NT];       // element offset of the column's q row / out row base (without ld)
+  long col_row[NT];       // token row of the column
   int col_head[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -82,10 +85,10 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
     col_head[nt] = kvh * g + hl;
   }
 
-  // kv block range of this split
+  // kv block range of this split; the 4 waves of the workgroup interleave its blocks.
+  // A row that ran past its table (a finished sequence still riding in a fixed-shape batch) is
+  // clamped to the table: reads stay in bounds, its output is discarded by the scheduler.
   const int tile_q_end = min(q_len, qp0 + QT);
-  // a row that ran past its table (a finished sequence still riding in a fixed-shape batch)
-  // is clamped to the table: reads stay in bounds, its output is discarded by the scheduler
   const int kv_len = tile_live ? min(ctx + tile_q_end, p.max_blocks * kBlockTokens) : 0;
   const int nb = (kv_len + kBlockTokens - 1) / kBlockTokens;
   const int per = (nb + p.splits - 1) / p.splits;
@@ -113,19 +116,22 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
   }
 
   const long slab = kv_slab_elems(D);
-  for (int kb = kb0; kb < kb1; ++kb) {
-    int blk = p.block_table[(long)srow * p.max_blocks + kb];
+  const int* table = p.block_table + (long)srow * p.max_blocks;
+  auto block_base = [&](int kb) -> const bf16* {
+    int blk = table[kb];
     blk = (srow_ok && blk >= 0 && blk < p.num_blocks) ? blk : 0;          // never a wild read
-    const bf16* kbase = p.kv + kv_head_base(blk, kvh, p.Hkv, D, 0) + lane * 8;
-    const bf16* vbase = kbase + slab;
-    u32x4 kf[2][KS], vf[DT];
+    return p.kv + kv_head_base(blk, kvh, p.Hkv, D, 0) + lane * 8;
+  };
+  auto load_kv = [&](const bf16* kbase, u32x4 (&kf)[2][KS], u32x4 (&vf)[DT]) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int s = 0; s < KS; ++s) kf[kt][s] = ld16(kbase + kt * 16 * D + s * 512);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld16(vbase + dt * 512);
+    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld16(kbase + slab + dt * 512);
+  };
 
+  auto process = [&](int kb, const u32x4 (&kf)[2][KS], const u32x4 (&vf)[DT]) {
     // S^T = K Q^T : st[kt][nt][r] = score(key = kb*32 + kt*16 + quad*4 + r, column nt*16+l15)
     f32x4 st[2][NT];
 #pragma unroll
@@ -137,7 +143,6 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
         for (int s = 0; s < KS; ++s) a = mfma16(kf[kt][s], qf[nt][s], a);
         st[kt][nt] = a;
       }
-
     u32x4 pf[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -148,9 +153,9 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kpos = kb * kBlockTokens + kt * 16 + quad * 4 + r;
-          const float s = kpos <= limit ? st[kt][nt][r] : kNegInf;
-          st[kt][nt][r] = s;
-          mx = fmaxf(mx, s);
+          const float sc = kpos <= limit ? st[kt][nt][r] : kNegInf;
+          st[kt][nt][r] = sc;
+          mx = fmaxf(mx, sc);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -176,30 +181,76 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[dt][nt] = mfma16(vf[dt], pf[nt], o[dt][nt]);
+  };
+
+  if constexpr (PREFETCH) {
+    u32x4 kfa[2][KS], vfa[DT], kfb[2][KS], vfb[DT];
+    int kb = kb0 + wave;
+    if (kb < kb1) load_kv(block_base(kb), kfa, vfa);
+    for (; kb < kb1; kb += 8) {
+      if (kb + 4 < kb1) load_kv(block_base(kb + 4), kfb, vfb);
+      process(kb, kfa, vfa);
+      if (kb + 4 < kb1) {
+        if (kb + 8 < kb1) load_kv(block_base(kb + 8), kfa, vfa);
+        process(kb + 4, kfb, vfb);
+      }
+    }
+  } else {
+    for (int kb = kb0 + wave; kb < kb1; kb += 4) {
+      u32x4 kf[2][KS], vf[DT];
+      load_kv(block_base(kb), kf, vf);
+      process(kb, kf, vf);
+    }
   }
 
+  // ---- merge the 4 waves through LDS -----------------------------------------------------
+  // layout: ml[w][nt][lane] = (m, l partial of this lane); oacc[w][dt][nt][lane] f32x4
+  float* ml = reinterpret_cast<float*>(smem);                         // 4 * NT * 64 * 2 floats
+  f32x4* oacc = reinterpret_cast<f32x4*>(smem + 4 * NT * 64 * 2 * 4);  // 4 * DT * NT * 64 f32x4
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     float lt = l[nt];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
+    ml[((wave * NT + nt) * 64 + lane) * 2] = m[nt];
+    ml[((wave * NT + nt) * 64 + lane) * 2 + 1] = lt;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[((wave * DT + dt) * NT + nt) * 64 + lane] = o[dt][nt];
+  }
+  __syncthreads();
+  // wave w merges the head-dim tiles dt = w, w+4, ...
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float mw[4], lw[4], mt = kNegInf;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      mw[w] = ml[((w * NT + nt) * 64 + lane) * 2];
+      lw[w] = ml[((w * NT + nt) * 64 + lane) * 2 + 1];
+      mt = fmaxf(mt, mw[w]);
+    }
+    const float m_safe = mt == kNegInf ? 0.f : mt;
+    float wgt[4], lt = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      wgt[w] = exp2f((mw[w] - m_safe) * p.scale_log2);      // -inf -> 0
+      lt += lw[w] * wgt[w];
+    }
     if (col_qpos[nt] < 0) continue;
-    if (p.splits == 1) {
-      const float inv = lt > 0.f ? 1.f / lt : 0.f;
-      bf16* orow = p.out + col_row[nt] * p.ldo + col_head[nt] * D + quad * 4;
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    for (int dt = wave; dt < DT; dt += 4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        u32x2 v = {pack_bf16(o[dt][nt][0] * inv, o[dt][nt][1] * inv),
-                   pack_bf16(o[dt][nt][2] * inv, o[dt][nt][3] * inv)};
-        *reinterpret_cast<u32x2*>(orow + dt * 16) = v;
+      for (int w = 0; w < 4; ++w) acc += oacc[((w * DT + dt) * NT + nt) * 64 + lane] * wgt[w];
+      if (p.splits == 1) {
+        u32x2 v = {pack_bf16(acc[0] * inv, acc[1] * inv), pack_bf16(acc[2] * inv, acc[3] * inv)};
+        *reinterpret_cast<u32x2*>(p.out + col_row[nt] * p.ldo + col_head[nt] * D + dt * 16 + quad * 4) = v;
+      } else {
+        // record = [m, l, pad, pad, O[D]] fp32 per (item, column), unnormalised
+        const long rec = ((((long)b * p.Hkv + kvh) * p.qtiles + qtile) * p.splits + split) * NC + nt * 16 + l15;
+        float* r = p.partial + rec * (D + 4);
+        if (quad == 0 && dt == wave) { r[0] = mt; r[1] = lt; }
+        *reinterpret_cast<f32x4*>(r + 4 + dt * 16 + quad * 4) = acc;
       }
-    } else {
-      // record = [m, l, pad, pad, O[D]] fp32 per (item, column)
-      const long rec = ((((long)b * p.Hkv + kvh) * p.qtiles + qtile) * p.splits + split) * NC + nt * 16 + l15;
-      float* r = p.partial + rec * (D + 4);
-      if (quad == 0) { r[0] = m[nt]; r[1] = lt; }
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(r + 4 + dt * 16 + quad * 4) = o[dt][nt];
     }
   }
 }
@@ -246,7 +297,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
 template <int D, int NT>
 static void launch_attn(const AttnParams& p, hipStream_t stream) {
   const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
-  hipLaunchKernelGGL((paged_attn_kernel<D, NT>), dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, stream, p);
+  constexpr size_t smem = 4 * NT * 64 * 2 * 4 + 4 * (D / 16) * NT * 64 * 16;
+  hipLaunchKernelGGL((paged_attn_kernel<D, NT>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   if (p.splits > 1)
     hipLaunchKernelGGL((attn_combine_kernel<D, NT>), dim3((unsigned)((long)p.B * p.Hkv * p.qtiles)), dim3(256), 0,
                        stream, p);

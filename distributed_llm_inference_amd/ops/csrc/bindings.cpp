@@ -42,13 +42,14 @@ inline void check_rows(const Tensor& t, const char* name) {
   DLIA_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0, name, " must be 16-byte aligned");
 }
 
-// out[r,:] = norm(x[row_idx[r] or r,:] (+delta -> x)) * w (+ b)
-void norm(Tensor out, Tensor x, OptTensor delta, const Tensor& w, OptTensor b, OptTensor row_idx,
-          double eps, bool layernorm) {
+// out[r,:] = norm(x[row_idx[r] or r,:] (+addend -> x)) * w (+ b); mode 0 rms, 1 layernorm, 2 fold only.
+void norm(Tensor out, Tensor x, OptTensor delta, OptTensor partial, int64_t splits, OptTensor pbias,
+          const Tensor& w, OptTensor b, OptTensor row_idx, double eps, int64_t mode) {
   check_bf16(out, "out"); check_bf16(x, "x"); check_bf16(w, "w");
   check_rows(out, "out"); check_rows(x, "x");
   const int64_t H = x.size(1);
   DLIA_CHECK(H % 8 == 0, "hidden size must be a multiple of 8");
+  DLIA_CHECK(mode >= 0 && mode <= 2, "norm mode");
   DLIA_CHECK(out.size(1) == H && w.numel() == H && w.is_contiguous(), "norm: shape mismatch");
   const int* ridx = nullptr;
   int64_t rows = x.size(0);
@@ -64,15 +65,28 @@ void norm(Tensor out, Tensor x, OptTensor delta, const Tensor& w, OptTensor b, O
     DLIA_CHECK(delta->sizes() == x.sizes() && delta->stride(0) == x.stride(0), "delta must match x");
     dp = delta->data_ptr();
   }
+  const float* pp = nullptr; const void* pb = nullptr; int64_t pM = x.size(0);
+  if (partial.has_value()) {
+    DLIA_CHECK(!delta.has_value(), "norm: delta and partial are exclusive");
+    check_f32(*partial, "partial");
+    DLIA_CHECK(splits >= 1 && partial->numel() >= splits * pM * H, "norm: partial workspace smaller than [splits, rows, H]");
+    pp = partial->data_ptr<float>();
+    if (pbias.has_value()) {
+      check_bf16(*pbias, "pbias");
+      DLIA_CHECK(pbias->numel() == H && pbias->is_contiguous(), "pbias shape");
+      pb = pbias->data_ptr();
+    }
+  }
+  DLIA_CHECK(mode != 2 || pp || dp, "norm mode 2 needs an addend");
   const void* bp = nullptr;
-  if (layernorm) {
+  if (mode == 1) {
     DLIA_CHECK(b.has_value(), "layernorm needs a bias");
     check_bf16(*b, "b");
     DLIA_CHECK(b->numel() == H && b->is_contiguous(), "bias shape");
     bp = b->data_ptr();
   }
-  dlia_norm(out.data_ptr(), x.data_ptr(), dp, w.data_ptr(), bp, ridx, (int)rows, (int)H, x.stride(0),
-            out.stride(0), (float)eps, layernorm ? 1 : 0, cur_stream());
+  dlia_norm(out.data_ptr(), x.data_ptr(), dp, pp, (int)splits, pM, pb, w.data_ptr(), bp, ridx, (int)rows, (int)H,
+            x.stride(0), out.stride(0), (float)eps, (int)mode, cur_stream());
 }
 
 void embed(Tensor out, const Tensor& ids, OptTensor pos, const Tensor& wte, OptTensor wpe) {
@@ -100,7 +114,8 @@ inline KvGeom check_kv(const Tensor& kv, int64_t Hkv, int64_t D) {
   return {kv.size(0)};
 }
 
-void rope_kvwrite(Tensor qkv, Tensor kv_cache, const Tensor& cos_t, const Tensor& sin_t,
+void rope_kvwrite(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias, Tensor kv_cache,
+                  const Tensor& cos_t, const Tensor& sin_t,
                   const Tensor& tok_pos, const Tensor& tok_seq, const Tensor& block_table,
                   int64_t Hq, int64_t Hkv, int64_t D, bool use_rope) {
   check_bf16(qkv, "qkv");
@@ -117,8 +132,19 @@ void rope_kvwrite(Tensor qkv, Tensor kv_cache, const Tensor& cos_t, const Tensor
     DLIA_CHECK(cos_t.dim() == 2 && cos_t.size(1) == D / 2 && sin_t.sizes() == cos_t.sizes(), "rope tables [P, D/2]");
     rope_len = (int)cos_t.size(0); cp = cos_t.data_ptr<float>(); sp = sin_t.data_ptr<float>();
   }
+  const float* pp = nullptr; const void* pb = nullptr;
+  if (partial.has_value()) {
+    check_f32(*partial, "partial");
+    DLIA_CHECK(splits >= 1 && partial->numel() >= splits * T * qkv.size(1), "rope: partial workspace smaller than [splits, T, W]");
+    pp = partial->data_ptr<float>();
+    if (pbias.has_value()) {
+      check_bf16(*pbias, "pbias");
+      DLIA_CHECK(pbias->numel() == qkv.size(1) && pbias->is_contiguous(), "pbias shape");
+      pb = pbias->data_ptr();
+    }
+  }
   // tok_seq values index block_table rows: the caller guarantees tok_seq < block_table.size(0)
-  dlia_rope_kvwrite(qkv.data_ptr(), kv_cache.data_ptr(), cp, sp, tok_pos.data_ptr<int>(), tok_seq.data_ptr<int>(),
+  dlia_rope_kvwrite(qkv.data_ptr(), pp, (int)splits, pb, kv_cache.data_ptr(), cp, sp, tok_pos.data_ptr<int>(), tok_seq.data_ptr<int>(),
                     block_table.data_ptr<int>(), (int)T, (int)Hq, (int)Hkv, (int)D, (int)block_table.size(1),
                     (int)g.num_blocks, rope_len, use_rope ? 1 : 0, cur_stream());
 }
@@ -126,12 +152,12 @@ void rope_kvwrite(Tensor qkv, Tensor kv_cache, const Tensor& cos_t, const Tensor
 // out[M, N_out] = epi(x[M,K] @ W^T); wp = packed weights (uint8 view of the packed image).
 // epi: 0 none, 1 +bias, 2 +residual, 3 +bias+residual, 4 swiglu, 5 +bias -> gelu_tanh.
 void gemm(Tensor out, const Tensor& x, const Tensor& wp, OptTensor bias, OptTensor residual,
-          OptTensor workspace, int64_t N, int64_t epi, int64_t splitk) {
+          OptTensor workspace, int64_t N, int64_t epi, int64_t splitk, int64_t ntw) {
   check_bf16(x, "x"); check_rows(x, "x"); check_dev(out, "out"); check_dev(wp, "wp");
   const int64_t M = x.size(0), K = x.size(1);
   DLIA_CHECK(K % 128 == 0, "K must be a multiple of 128");
   DLIA_CHECK(N % 4 == 0, "N must be a multiple of 4");
-  DLIA_CHECK(epi >= 0 && epi <= 5, "bad epilogue");
+  DLIA_CHECK(epi >= 0 && epi <= 6, "bad epilogue");
   const int64_t n_pad = (N + 127) / 128 * 128;
   DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == n_pad * K * 2,
              "packed weight has ", wp.numel() * wp.element_size(), " bytes, expected ", n_pad * K * 2);
@@ -140,7 +166,7 @@ void gemm(Tensor out, const Tensor& x, const Tensor& wp, OptTensor bias, OptTens
   if (epi == 4) DLIA_CHECK(N % 32 == 0, "swiglu needs gate/up tile pairs");
   const bool f32 = out.scalar_type() == at::kFloat;
   DLIA_CHECK(f32 || out.scalar_type() == at::kBFloat16, "out must be bf16 or fp32");
-  DLIA_CHECK(out.dim() == 2 && out.stride(1) == 1 && out.size(0) >= M && out.size(1) >= n_out, "out shape");
+  DLIA_CHECK(epi == 6 || (out.dim() == 2 && out.stride(1) == 1 && out.size(0) >= M && out.size(1) >= n_out), "out shape");
   DLIA_CHECK(out.stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0, "out alignment");
   const void* bp = nullptr; const void* rp = nullptr; long ldr = 0;
   if (epi == 1 || epi == 3 || epi == 5) {
@@ -156,27 +182,45 @@ void gemm(Tensor out, const Tensor& x, const Tensor& wp, OptTensor bias, OptTens
     rp = residual->data_ptr(); ldr = residual->stride(0);
   }
   auto stream = cur_stream();
-  if (M <= 64) {
+  if (M <= 128) {
     float* ws = nullptr;
-    int sk = (int)splitk;
-    if (sk <= 0) sk = dlia_gemm_skinny_splitk((int)M, (int)N, (int)K);
-    if (workspace.has_value() && sk > 1) {
+    int sk = (int)splitk, nt = (int)ntw;
+    if (sk <= 0 || nt <= 0) {
+      int an, as;
+      dlia_gemm_skinny_config((int)M, (int)N, (int)K, (int)epi, workspace.has_value() ? 1 : 0, &an, &as);
+      if (sk <= 0) sk = as;
+      if (nt <= 0) nt = an;
+    }
+    if (workspace.has_value()) {
       check_f32(*workspace, "workspace");
       const int64_t have = workspace->numel();
-      while (sk > 1 && have < (int64_t)sk * M * N) sk /= 2;      // shrink rather than overrun
+      if (epi == 6) {
+        DLIA_CHECK(have >= (int64_t)sk * M * N, "gemm: partial workspace smaller than [splitk, M, N]");
+      } else {
+        while (sk > 1 && have < (int64_t)sk * M * N) sk /= 2;      // shrink rather than overrun
+      }
       ws = workspace->data_ptr<float>();
     } else {
+      DLIA_CHECK(epi != 6, "partial output needs a workspace");
       sk = 1;
     }
     dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, ws, nullptr, (int)M, (int)N, (int)K,
-                     x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, stream);
+                     x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, nt, stream);
   } else {
+    DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 128) feature");
     dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
                    out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
   }
 }
 
 int64_t gemm_splitk(int64_t M, int64_t N, int64_t K) { return dlia_gemm_skinny_splitk((int)M, (int)N, (int)K); }
+
+// [ntw, splitk] the weight-streaming kernel would use for this shape
+std::vector<int64_t> gemm_config(int64_t M, int64_t N, int64_t K, int64_t epi, bool allow_split) {
+  int ntw, sk;
+  dlia_gemm_skinny_config((int)M, (int)N, (int)K, (int)epi, allow_split ? 1 : 0, &ntw, &sk);
+  return {ntw, sk};
+}
 
 int64_t attention_ws_floats(int64_t B, int64_t max_q_len, int64_t Hq, int64_t Hkv, int64_t D, int64_t splits) {
   return dlia_paged_attention_ws_floats((int)B, (int)max_q_len, (int)Hq, (int)Hkv, (int)D, (int)splits);
@@ -229,6 +273,8 @@ void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, 
   DLIA_CHECK(logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1, "logits must be fp32 [R, >=vocab]");
   const int64_t R = logits.size(0);
   DLIA_CHECK(vocab > 0 && vocab <= logits.size(1), "vocab out of range");
+  DLIA_CHECK(logits.stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(logits.data_ptr()) % 16 == 0,
+             "logits rows must be 16-byte aligned");
   check_f32(temperature, "temperature"); check_i32(top_k, "top_k"); check_f32(top_p, "top_p"); check_i32(steps, "steps");
   check_dev(seeds, "seeds");
   DLIA_CHECK(seeds.scalar_type() == at::kLong && seeds.is_contiguous(), "seeds must be int64");
@@ -255,10 +301,11 @@ void advance(Tensor x, int64_t delta) {
 }  // namespace
 
 TORCH_LIBRARY(dlia, m) {
-  m.def("norm(Tensor(a!) out, Tensor(b!) x, Tensor? delta, Tensor w, Tensor? b, Tensor? row_idx, float eps, bool layernorm) -> ()");
+  m.def("norm(Tensor(a!) out, Tensor(b!) x, Tensor? delta, Tensor? partial, int splits, Tensor? pbias, Tensor w, Tensor? b, Tensor? row_idx, float eps, int mode) -> ()");
   m.def("embed(Tensor(a!) out, Tensor ids, Tensor? pos, Tensor wte, Tensor? wpe) -> ()");
-  m.def("rope_kvwrite(Tensor(a!) qkv, Tensor(b!) kv_cache, Tensor cos, Tensor sin, Tensor tok_pos, Tensor tok_seq, Tensor block_table, int Hq, int Hkv, int D, bool use_rope) -> ()");
-  m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk) -> ()");
+  m.def("rope_kvwrite(Tensor(a!) qkv, Tensor? partial, int splits, Tensor? pbias, Tensor(b!) kv_cache, Tensor cos, Tensor sin, Tensor tok_pos, Tensor tok_seq, Tensor block_table, int Hq, int Hkv, int D, bool use_rope) -> ()");
+  m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
+  m.def("gemm_config(int M, int N, int K, int epi, bool allow_split) -> int[]");
   m.def("gemm_splitk(int M, int N, int K) -> int");
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
   m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
@@ -278,5 +325,6 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
 
 TORCH_LIBRARY_IMPL(dlia, CompositeExplicitAutograd, m) {
   m.impl("gemm_splitk", &gemm_splitk);
+  m.impl("gemm_config", &gemm_config);
   m.impl("attention_ws_floats", &attention_ws_floats);
 }

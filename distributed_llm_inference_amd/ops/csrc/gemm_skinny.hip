@@ -31,6 +31,32 @@ namespace dlia {
 constexpr int kSkinnyBK = 128;       // K elements per LDS stage (4 MFMA k-steps)
 constexpr int kSkinnyThreads = 256;  // 4 waves
 
+template <int V> struct IntC { static constexpr int value = V; };
+
+// The loads of the main loop are issued through inline asm and waited for with hand-counted
+// s_waitcnt vmcnt(N): hipcc's own wait insertion loses track of loads that stay in flight across
+// the loop back-edge and drains the queue every chunk, which collapses the prefetch depth. The
+// counter is in-order, so "all but the N youngest are done" is exact as long as EVERY load in
+// the loop goes through these helpers (the compiler then emits no vmcnt of its own in there).
+//
+// The compiler believes a destination is valid as soon as the load statement has executed, so
+// the contract has two halves: (1) no consumer may be scheduled above its wait — the wait
+// clobbers memory (orders the LDS stores) and is followed by a scheduling barrier (orders the
+// MFMAs); (2) the compiler must not COPY a destination between load and wait. A register-tied
+// wait operand provoked exactly such copies in the peeled tail, so the wait names no registers.
+// ops/isa_lint.py re-checks (2) on the generated ISA at build time.
+__device__ __forceinline__ void gload16(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+__device__ __forceinline__ void gload16_nt(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int MT, int NTW>
 __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (MT*16 rows x 256 B)
@@ -43,8 +69,9 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
   const int cper = (chunks_total + p.splitk - 1) / p.splitk;
   const int c0 = ks * cper;
   const int c1 = min(chunks_total, c0 + cper);
+  const int n = c1 - c0;                         // LDS stages (chunks of 128 K-elements) of this split
   const int tile0 = (nblk * 4 + wave) * NTW;     // first n-tile of this wave
-  const bool wave_active = tile0 < p.ntiles;     // (ntiles is a multiple of 4*NTW by packing)
+  const bool wave_active = tile0 < p.ntiles;     // (ntiles is a multiple of 8 by packing)
 
   // x staging map: thread -> (row = tid/16 + 16 i, 16-B slot = tid%16), slot XOR-swizzled by row&15
   const int srow = tid >> 4, sslot = tid & 15;
@@ -54,13 +81,13 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
   for (int i = 0; i < MT; ++i) {
     const int r = srow + 16 * i;
     const int rc = r < p.M ? r : p.M - 1;        // rows past M re-read the last row; never stored
-    xsrc[i] = p.x + (long)rc * p.ldx + sslot * 8;
+    xsrc[i] = p.x + (long)rc * p.ldx + sslot * 8 + (long)c0 * kSkinnyBK;
     xdst[i] = r * 256 + ((sslot ^ (r & 15)) << 4);
   }
   const u32x4* wbase[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
-    wbase[j] = p.wp + ((long)(wave_active ? tile0 + j : 0) * KT) * 64 + lane;
+    wbase[j] = p.wp + ((long)(wave_active ? tile0 + j : 0) * KT + (long)c0 * 4) * 64 + lane;
 
   f32x4 acc[MT][NTW];
 #pragma unroll
@@ -68,57 +95,97 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (c0 < c1) {
-    u32x4 wcur[4][NTW], wnext[4][NTW], xr[MT];
-    // prologue: chunk c0
+  if (n > 0) {
+    // Weight ring: 2 chunks (8 k-steps) deep. Slot (par*4 + kk) holds k-step kk of the chunk with
+    // parity par and is refilled with the chunk two ahead right after its last use, so up to
+    // 16 KiB of weights per wave stay in flight — also across the per-chunk barrier, which only
+    // orders the two LDS stages of x.
+    // Issue order (per chunk c, after the prologue): x(c+2) [MT loads], then per k-step kk the
+    // refill of slot kk [NTW loads]. Hence, in steady state:
+    //   x(c+1) has 4*NTW younger loads when chunk c starts        -> vmcnt(4*NTW)
+    //   slot kk of chunk c has 7*NTW + 2*MT younger loads at its use -> vmcnt(7*NTW + 2*MT)
+    constexpr int kWaitX = 4 * NTW, kWaitW = 7 * NTW + 2 * MT;
+    static_assert(kWaitW <= 63, "vmcnt is a 6-bit counter");
+    u32x4 w[8][NTW], xr[MT];
+    // prologue, in the same order as the steady state: x(0) | w(0) | x(1) | w(1)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) xr[i] = ld16(xsrc[i] + (long)c0 * kSkinnyBK);
+    for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) wcur[kk][j] = ld16_nt(wbase[j] + (long)(c0 * 4 + kk) * 64);
+      for (int j = 0; j < NTW; ++j) gload16_nt(w[kk][j], wbase[j] + (long)kk * 64);
+    // x(0) -> LDS needs only x(0): 4*NTW younger loads
+    wait_vm<4 * NTW>();
 #pragma unroll
     for (int i = 0; i < MT; ++i) st16(smem + xdst[i], xr[i]);
+    if (n > 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i] + kSkinnyBK);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) gload16_nt(w[4 + kk][j], wbase[j] + (long)(4 + kk) * 64);
+    }
     __syncthreads();
 
-    for (int c = c0; c < c1; ++c) {
-      const int buf = (c - c0) & 1;
-      const bool more = c + 1 < c1;
-      if (more) {
+    // One chunk. REFILL: chunk c+2 exists (steady state, counted waits); otherwise this is one of
+    // the last two chunks: nothing new is issued and everything outstanding is drained first.
+    auto body = [&](auto PAR, auto REFILL, int c) {
+      constexpr int par = decltype(PAR)::value;
+      constexpr bool refill = decltype(REFILL)::value != 0;
+      if constexpr (refill) {
+        char* xn = smem + (par ^ 1) * kStageBytes;
+        wait_vm<kWaitX>();
 #pragma unroll
-        for (int i = 0; i < MT; ++i) xr[i] = ld16(xsrc[i] + (long)(c + 1) * kSkinnyBK);
+        for (int i = 0; i < MT; ++i) st16(xn + xdst[i], xr[i]);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i] + (long)(c + 2) * kSkinnyBK);
+      } else {
+        wait_vm<0>();
+        if (c + 1 < n) {
+          char* xn = smem + (par ^ 1) * kStageBytes;
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) wnext[kk][j] = ld16_nt(wbase[j] + (long)((c + 1) * 4 + kk) * 64);
+          for (int i = 0; i < MT; ++i) st16(xn + xdst[i], xr[i]);
+        }
       }
-      const char* xb = smem + buf * kStageBytes;
+      const char* xb = smem + par * kStageBytes;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
+        if constexpr (refill) wait_vm<kWaitW>();
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int r = i * 16 + l15;
           const u32x4 xf = *reinterpret_cast<const u32x4*>(xb + r * 256 + (((kk * 4 + quad) ^ l15) << 4));
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(wcur[kk][j], xf, acc[i][j]);
+          for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(w[par * 4 + kk][j], xf, acc[i][j]);
+        }
+        if constexpr (refill) {
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) gload16_nt(w[par * 4 + kk][j], wbase[j] + (long)((c + 2) * 4 + kk) * 64);
         }
       }
-      if (more) {
-        char* xn = smem + (buf ^ 1) * kStageBytes;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) st16(xn + xdst[i], xr[i]);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) wcur[kk][j] = wnext[kk][j];
-      }
       __syncthreads();
+    };
+    int c = 0;
+    for (; c + 3 < n; c += 2) {                  // both chunks of the pair have a chunk two ahead
+      body(IntC<0>{}, IntC<1>{}, c);
+      body(IntC<1>{}, IntC<1>{}, c + 1);
+    }
+    if (n - c == 3) {
+      body(IntC<0>{}, IntC<1>{}, c);
+      body(IntC<1>{}, IntC<0>{}, c + 1);
+      body(IntC<0>{}, IntC<0>{}, c + 2);
+    } else if (n - c == 2) {
+      body(IntC<0>{}, IntC<0>{}, c);
+      body(IntC<1>{}, IntC<0>{}, c + 1);
+    } else {
+      body(IntC<0>{}, IntC<0>{}, c);
     }
   }
   if (!wave_active) return;
 
   // acc[i][j][r] = C[m = i*16 + l15][n = (tile0+j)*16 + quad*4 + r]
-  if (p.splitk > 1) {
+  if (p.partial_only || p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = i * 16 + l15;
@@ -138,7 +205,6 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
     if (m >= p.M) continue;
     if (p.act == 1) {
       // tiles (2t, 2t+1) = (gate, up) rows of output columns [16t, 16t+16)
-      static_assert(NTW % 2 == 0 || NTW == 1, "swiglu needs gate/up tile pairs in one wave");
       if constexpr (NTW >= 2) {
 #pragma unroll
         for (int j = 0; j < NTW; j += 2) {
@@ -195,25 +261,48 @@ static void launch_skinny(const GemmParams& p, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW>), grid, block, smem, stream, p);
 }
 
+template <int MT>
+static void launch_skinny_ntw(const GemmParams& p, int ntw, hipStream_t stream) {
+  if (ntw == 1) launch_skinny<MT, 1>(p, stream);
+  else          launch_skinny<MT, 2>(p, stream);
+}
+
 }  // namespace dlia
 
 using namespace dlia;
 
-extern "C" int dlia_gemm_skinny_splitk(int M, int N, int K) {
-  // Aim for >= ~512 workgroups (2 per CU) while keeping >= 4 LDS stages (512 K-elements) per split.
-  const int ntw = 2;
-  const int nblocks = (packed_ntiles(N) + 4 * ntw - 1) / (4 * ntw);
+// Decomposition choice (calibrated with bench/gemm_sweep.py on MI355X). A workgroup streams 128
+// weight columns (2 n-tiles per wave): that re-reads x least. Shapes with fewer than 256 column
+// blocks are split along K until every CU has a workgroup — measured optimum for the Llama-3-8B
+// decode shapes (QKV 48 blocks -> 8 splits, O 32 -> 8, down 32 -> 8, gate/up 224 -> 2, lm_head
+// 1002 -> 1) — as long as a split keeps >= 2 LDS stages and the fp32 partials stay under ~20 MB
+// (at 128 rows QKV drops to 4 splits and gate/up to 1, also the measured optimum).
+extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_split, int* ntw_out, int* splitk_out) {
+  const int tiles = packed_ntiles(N);
   const int chunks = K / kSkinnyBK;
+  const int ntw = 2;
+  const int nblocks = (tiles + 4 * ntw - 1) / (4 * ntw);
   int s = 1;
-  while (nblocks * s < 384 && chunks / (s * 2) >= 4 && s < 16) s *= 2;
-  (void)M;
+  if (allow_split) {
+    while (nblocks * s < 256 && s < 16 && chunks / (s * 2) >= 2) s *= 2;
+    while (s > 1 && (double)s * M * N * 4.0 > 20.0e6) s /= 2;     // cap the fp32 partial traffic
+  }
+  (void)epi;
+  *ntw_out = ntw; *splitk_out = s;
+}
+
+extern "C" int dlia_gemm_skinny_splitk(int M, int N, int K) {
+  int ntw, s;
+  dlia_gemm_skinny_config(M, N, K, 0, 1, &ntw, &s);
   return s;
 }
 
+// epi: 0..5 as documented in launch.h; 6 = write fp32 partials [splitk][M][N] only (the consumer
+// kernel sums them). splitk / ntw <= 0 pick the heuristic.
 extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const void* bias,
                                  const void* residual, float* workspace, unsigned* counters,
                                  int M, int N, int K, long ldx, long ldo, long ldr, int epi,
-                                 int out_f32, int splitk, hipStream_t stream) {
+                                 int out_f32, int splitk, int ntw, hipStream_t stream) {
   (void)counters;
   if (M <= 0 || N <= 0) return;
   GemmParams p;
@@ -224,15 +313,21 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
   p.ntiles = packed_ntiles(N);
   p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
   p.out_f32 = out_f32;
-  if (splitk <= 0) splitk = dlia_gemm_skinny_splitk(M, N, K);
+  p.partial_only = epi == 6 ? 1 : 0;
+  int antw, as;
+  dlia_gemm_skinny_config(M, N, K, epi, workspace != nullptr, &antw, &as);
+  if (splitk <= 0) splitk = as;
+  if (ntw <= 0) ntw = antw;
+  if (epi == 4) ntw = 2;
   if (workspace == nullptr) splitk = 1;
   const int chunks = K / kSkinnyBK;
   if (splitk > chunks) splitk = chunks;
   p.splitk = splitk;
-  if (M <= 16)      launch_skinny<1, 2>(p, stream);
-  else if (M <= 32) launch_skinny<2, 2>(p, stream);
-  else              launch_skinny<4, 2>(p, stream);
-  if (splitk > 1) {
+  if (M <= 16)      launch_skinny_ntw<1>(p, ntw, stream);
+  else if (M <= 32) launch_skinny_ntw<2>(p, ntw, stream);
+  else if (M <= 64) launch_skinny_ntw<4>(p, ntw, stream);
+  else              launch_skinny_ntw<8>(p, ntw, stream);
+  if (splitk > 1 && !p.partial_only) {
     const int nout = p.act == 1 ? N / 2 : N;
     const long work = (long)M * (nout / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p);

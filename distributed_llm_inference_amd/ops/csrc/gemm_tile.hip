@@ -150,6 +150,7 @@ extern "C" void dlia_gemm_tile(void* out, const void* x, const void* wp, const v
   p.splitk = 1;
   p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
   p.out_f32 = out_f32;
+  p.partial_only = 0;
   const int tiles_m = (M + kTileM - 1) / kTileM;
   const int tiles_n = p.ntiles / (kTileN / 16);
   hipLaunchKernelGGL(gemm_tile_kernel, dim3(tiles_m * tiles_n), dim3(kTileThreads), 2 * kTileStageBytes,

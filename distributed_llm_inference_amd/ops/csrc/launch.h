@@ -7,10 +7,12 @@
 extern "C" {
 
 // ---- norm.hip -------------------------------------------------------------------------
-// out[r,:] = norm(x[row_idx ? row_idx[r] : r,:] (+ delta, written back into x)) * w (+ b)
-void dlia_norm(void* out, void* x, const void* delta, const void* w, const void* b,
-               const int* row_idx, int rows, int H, long ldx, long ldo, float eps,
-               int layernorm, hipStream_t stream);
+// out[r,:] = norm(x[row_idx ? row_idx[r] : r,:] (+ addend, written back into x)) * w (+ b).
+// addend: `delta` (bf16 rows) or the fp32 split-K partials [splits][pM][H] of the preceding GEMM
+// (+ pbias). mode: 0 RMSNorm, 1 LayerNorm, 2 only fold the addend into x.
+void dlia_norm(void* out, void* x, const void* delta, const float* partial, int splits, long pM,
+               const void* pbias, const void* w, const void* b, const int* row_idx, int rows, int H,
+               long ldx, long ldo, float eps, int mode, hipStream_t stream);
 
 // ---- embed.hip ------------------------------------------------------------------------
 // out[t,:] = wte[ids[t],:] (+ wpe[pos[t],:])
@@ -20,20 +22,25 @@ void dlia_embed(void* out, const int* ids, const int* pos, const void* wte, cons
 // ---- rope_kv.hip ----------------------------------------------------------------------
 // RoPE on the q and k slices of a fused qkv activation (in place on q), and scatter of the
 // (rotated) k and v rows into the paged, MFMA-fragment-ordered KV cache.
-void dlia_rope_kvwrite(void* qkv, void* kv_cache, const float* cos_t, const float* sin_t,
+// The q/k/v values come from `qkv` itself, or (partial != null) from the fp32 split-K partials
+// [splits][T][(Hq+2Hkv)*D] (+ pbias) of the QKV GEMM; the rotated q is written to `qkv` either way.
+void dlia_rope_kvwrite(void* qkv, const float* partial, int splits, const void* pbias, void* kv_cache,
+                       const float* cos_t, const float* sin_t,
                        const int* tok_pos, const int* tok_seq, const int* block_table,
                        int T, int Hq, int Hkv, int D, int max_blocks, int num_blocks,
                        int rope_len, int use_rope, hipStream_t stream);
 
 // ---- gemm_skinny.hip ------------------------------------------------------------------
-// out[M,N] = epilogue(x[M,K] @ Wp^T), M <= 64 per call (weight-streaming regime).
+// out[M,N] = epilogue(x[M,K] @ Wp^T), M <= 128 per call (weight-streaming regime).
 // epi: 0 none, 1 +bias, 2 +residual, 3 +bias+residual, 4 swiglu (interleaved gate/up tiles,
-// N = 2*N_out), 5 +bias then gelu_tanh. out_f32: write fp32 instead of bf16.
+// N = 2*N_out), 5 +bias then gelu_tanh, 6 fp32 partials [splitk][M][N] only (summed by the
+// consumer kernel). out_f32: write fp32 instead of bf16.
 void dlia_gemm_skinny(void* out, const void* x, const void* wp, const void* bias,
                       const void* residual, float* workspace, unsigned* counters,
                       int M, int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32,
-                      int splitk, hipStream_t stream);
-// heuristic split-K factor the launcher would choose (so callers can size the workspace)
+                      int splitk, int ntw, hipStream_t stream);
+// the decomposition the launcher would choose: n-tiles per wave and split-K factor
+void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_split, int* ntw_out, int* splitk_out);
 int dlia_gemm_skinny_splitk(int M, int N, int K);
 
 // ---- gemm_tile.hip --------------------------------------------------------------------

@@ -12,17 +12,20 @@ namespace dlia {
 
 constexpr int kNormThreads = 256;
 
-// MODE 0: RMSNorm, MODE 1: LayerNorm (weight + bias)
-template <int MODE, bool ADD>
+// MODE 0: RMSNorm, 1: LayerNorm (weight + bias), 2: no norm (only fold the addend into x).
+// SRC 0: x as is; 1: x += delta (bf16 [rows,H]); 2: x += sum_s partial[s] (+ pbias) where partial
+// is the fp32 [S][M][H] split-K output of the preceding GEMM — the reduction of those partials
+// costs no launch of its own. In modes 1/2 the updated residual stream is written back into x.
+template <int MODE, int SRC>
 __global__ __launch_bounds__(kNormThreads) void norm_kernel(
     bf16* __restrict__ out, bf16* __restrict__ x, const bf16* __restrict__ delta,
+    const float* __restrict__ partial, int splits, long pM, const bf16* __restrict__ pbias,
     const bf16* __restrict__ w, const bf16* __restrict__ b, const int* __restrict__ row_idx,
     int H, long ldx, long ldo, float eps) {
   __shared__ float scratch[16];
   const int orow = blockIdx.x;
   const long irow = row_idx ? row_idx[orow] : orow;
   bf16* xr = x + irow * ldx;
-  const bf16* dr = ADD ? delta + irow * ldx : nullptr;
   bf16* outr = out + (long)orow * ldo;
   const int nvec = H >> 3;
 
@@ -30,11 +33,41 @@ __global__ __launch_bounds__(kNormThreads) void norm_kernel(
   for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
     float f[8];
     unpack8(ld16(xr + i * 8), f);
-    if (ADD) {
+    if (SRC == 1) {
       float d[8];
-      unpack8(ld16(dr + i * 8), d);
+      unpack8(ld16(delta + irow * ldx + i * 8), d);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] += d[j];
+    } else if (SRC == 2) {
+      const float* pr = partial + irow * H + i * 8;
+      const long ss = pM * (long)H;                  // stride between splits
+      int s = 0;
+      for (; s + 4 <= splits; s += 4) {              // 8 independent 16-B loads in flight
+        f32x4 a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = *reinterpret_cast<const f32x4*>(pr + (s + u) * ss);
+          c[u] = *reinterpret_cast<const f32x4*>(pr + (s + u) * ss + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f[0] += a[u][0]; f[1] += a[u][1]; f[2] += a[u][2]; f[3] += a[u][3];
+          f[4] += c[u][0]; f[5] += c[u][1]; f[6] += c[u][2]; f[7] += c[u][3];
+        }
+      }
+      for (; s < splits; ++s) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pr + s * ss), c = *reinterpret_cast<const f32x4*>(pr + s * ss + 4);
+        f[0] += a[0]; f[1] += a[1]; f[2] += a[2]; f[3] += a[3];
+        f[4] += c[0]; f[5] += c[1]; f[6] += c[2]; f[7] += c[3];
+      }
+      if (pbias) {
+        float d[8];
+        unpack8(ld16(pbias + i * 8), d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += d[j];
+      }
+    }
+    if (SRC != 0) {
       u32x4 hv = pack8(f);
       st16(xr + i * 8, hv);           // residual stream updated in place
       unpack8(hv, f);                 // statistics on the rounded value, as an unfused add would see it
@@ -42,7 +75,9 @@ __global__ __launch_bounds__(kNormThreads) void norm_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1 += f[j]; s2 += f[j] * f[j]; }
   }
+  if (MODE == 2) return;
   float mean = 0.f, rstd;
+  if (SRC != 0) __syncthreads();      // the passes below re-read x: make this block's stores visible
   if (MODE == 0) {
     s2 = block_sum(s2, scratch);
     rstd = rsqrtf(s2 / H + eps);
@@ -81,18 +116,21 @@ __global__ __launch_bounds__(kNormThreads) void norm_kernel(
 
 using namespace dlia;
 
-extern "C" void dlia_norm(void* out, void* x, const void* delta, const void* w, const void* b,
-                          const int* row_idx, int rows, int H, long ldx, long ldo, float eps,
-                          int layernorm, hipStream_t stream) {
+// mode: 0 RMSNorm, 1 LayerNorm, 2 none (fold the addend into x only). Addend: `delta` (bf16) or
+// `partial` (fp32 [splits][pM][H] + optional bias), at most one of them.
+extern "C" void dlia_norm(void* out, void* x, const void* delta, const float* partial, int splits, long pM,
+                          const void* pbias, const void* w, const void* b, const int* row_idx, int rows, int H,
+                          long ldx, long ldo, float eps, int mode, hipStream_t stream) {
   if (rows <= 0) return;
   dim3 grid(rows), block(kNormThreads);
   bf16* o = (bf16*)out; bf16* xx = (bf16*)x;
   const bf16* d = (const bf16*)delta; const bf16* ww = (const bf16*)w; const bf16* bb = (const bf16*)b;
-  if (layernorm) {
-    if (delta) hipLaunchKernelGGL((norm_kernel<1, true>), grid, block, 0, stream, o, xx, d, ww, bb, row_idx, H, ldx, ldo, eps);
-    else       hipLaunchKernelGGL((norm_kernel<1, false>), grid, block, 0, stream, o, xx, d, ww, bb, row_idx, H, ldx, ldo, eps);
-  } else {
-    if (delta) hipLaunchKernelGGL((norm_kernel<0, true>), grid, block, 0, stream, o, xx, d, ww, bb, row_idx, H, ldx, ldo, eps);
-    else       hipLaunchKernelGGL((norm_kernel<0, false>), grid, block, 0, stream, o, xx, d, ww, bb, row_idx, H, ldx, ldo, eps);
-  }
+  const bf16* pb = (const bf16*)pbias;
+  const int src = partial ? 2 : (delta ? 1 : 0);
+#define DLIA_NORM(MODE, SRC) hipLaunchKernelGGL((norm_kernel<MODE, SRC>), grid, block, 0, stream, o, xx, d, partial, \
+                                                splits, pM, pb, ww, bb, row_idx, H, ldx, ldo, eps)
+  if (mode == 0)      { if (src == 0) DLIA_NORM(0, 0); else if (src == 1) DLIA_NORM(0, 1); else DLIA_NORM(0, 2); }
+  else if (mode == 1) { if (src == 0) DLIA_NORM(1, 0); else if (src == 1) DLIA_NORM(1, 1); else DLIA_NORM(1, 2); }
+  else                { if (src == 1) DLIA_NORM(2, 1); else if (src == 2) DLIA_NORM(2, 2); }
+#undef DLIA_NORM
 }

@@ -13,9 +13,52 @@
 
 namespace dlia {
 
+// Loads 8 consecutive columns [col, col+8) of token row t: from the bf16 activation, or — when the
+// QKV GEMM ran split-K — as the sum of its fp32 partials (+ bias), which folds that reduction
+// into this kernel.
+struct QkvSrc {
+  const bf16* row;            // bf16 path: this token's row
+  const float* partial;       // fp32 [S][T][W] or null
+  const bf16* bias;
+  int splits; long T; long t; int W;
+  __device__ __forceinline__ void load8(int col, float (&f)[8]) const {
+    if (!partial) { unpack8(ld16(row + col), f); return; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = 0.f;
+    const float* pr = partial + (long)t * W + col;
+    const long ss = T * (long)W;                     // stride between splits
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {                // 8 independent 16-B loads in flight
+      f32x4 a[4], c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = *reinterpret_cast<const f32x4*>(pr + (s + u) * ss);
+        c[u] = *reinterpret_cast<const f32x4*>(pr + (s + u) * ss + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f[0] += a[u][0]; f[1] += a[u][1]; f[2] += a[u][2]; f[3] += a[u][3];
+        f[4] += c[u][0]; f[5] += c[u][1]; f[6] += c[u][2]; f[7] += c[u][3];
+      }
+    }
+    for (; s < splits; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(pr + s * ss), c = *reinterpret_cast<const f32x4*>(pr + s * ss + 4);
+      f[0] += a[0]; f[1] += a[1]; f[2] += a[2]; f[3] += a[3];
+      f[4] += c[0]; f[5] += c[1]; f[6] += c[2]; f[7] += c[3];
+    }
+    if (bias) {
+      float d[8];
+      unpack8(ld16(bias + col), d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += d[j];
+    }
+  }
+};
+
 template <bool ROPE>
 __global__ __launch_bounds__(256) void rope_kvwrite_kernel(
-    bf16* __restrict__ qkv, bf16* __restrict__ kv, const float* __restrict__ cos_t,
+    bf16* __restrict__ qkv, const float* __restrict__ partial, int splits, const bf16* __restrict__ pbias, int T,
+    bf16* __restrict__ kv, const float* __restrict__ cos_t,
     const float* __restrict__ sin_t, const int* __restrict__ tok_pos, const int* __restrict__ tok_seq,
     const int* __restrict__ block_table, int Hq, int Hkv, int D, int max_blocks, int num_blocks, int rope_len) {
   const int t = blockIdx.x;
@@ -28,16 +71,18 @@ __global__ __launch_bounds__(256) void rope_kvwrite_kernel(
   const bool kv_ok = blk >= 0 && blk < num_blocks;   // an unallocated slot is skipped, never a wild store
   const int half = D >> 1, octs = half >> 3;
   bf16* row = qkv + (long)t * (Hq + 2 * Hkv) * D;
+  const QkvSrc src{row, partial, pbias, splits, (long)T, (long)t, (Hq + 2 * Hkv) * D};
 
   const int nrot = (Hq + Hkv) * octs;
-  for (int it = threadIdx.x; it < nrot; it += 256) {
+  const int tstep = 256 * gridDim.y;
+  for (int it = threadIdx.x + 256 * blockIdx.y; it < nrot; it += tstep) {
     const int head = it / octs, o = it - head * octs;
     bf16* p = row + head * D + o * 8;
     const bool is_k = head >= Hq;
-    if (!ROPE && !is_k) continue;
+    if (!ROPE && !is_k && !partial) continue;     // q is already in place and needs no rotation
     float lo[8], hi[8];
-    unpack8(ld16(p), lo);
-    unpack8(ld16(p + half), hi);
+    src.load8(head * D + o * 8, lo);
+    src.load8(head * D + o * 8 + half, hi);
     if (ROPE) {
       const int rp = pos < 0 ? 0 : (pos >= rope_len ? rope_len - 1 : pos);   // table reads stay in bounds
       const float* cp = cos_t + (long)rp * half + o * 8;
@@ -65,11 +110,12 @@ __global__ __launch_bounds__(256) void rope_kvwrite_kernel(
   if (!kv_ok) return;
   const int vocts = D >> 3;
   const int nv = Hkv * vocts;
-  const unsigned short* vrow = reinterpret_cast<const unsigned short*>(row + (Hq + Hkv) * D);
   unsigned short* kvs = reinterpret_cast<unsigned short*>(kv);
-  for (int it = threadIdx.x; it < nv; it += 256) {
+  for (int it = threadIdx.x + 256 * blockIdx.y; it < nv; it += tstep) {
     const int h = it / vocts, o = it - h * vocts;
-    const u32x4 v = ld16(vrow + h * D + o * 8);
+    float vf[8];
+    src.load8((Hq + Hkv) * D + h * D + o * 8, vf);
+    const u32x4 v = pack8(vf);
     unsigned short* base = kvs + kv_head_base(blk, h, Hkv, D, 1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -81,16 +127,23 @@ __global__ __launch_bounds__(256) void rope_kvwrite_kernel(
 
 }  // namespace dlia
 
-extern "C" void dlia_rope_kvwrite(void* qkv, void* kv_cache, const float* cos_t, const float* sin_t,
+extern "C" void dlia_rope_kvwrite(void* qkv, const float* partial, int splits, const void* pbias, void* kv_cache,
+                                  const float* cos_t, const float* sin_t,
                                   const int* tok_pos, const int* tok_seq, const int* block_table,
                                   int T, int Hq, int Hkv, int D, int max_blocks, int num_blocks,
                                   int rope_len, int use_rope, hipStream_t stream) {
   if (T <= 0) return;
   using namespace dlia;
+  // few tokens (decode): spread each token's heads over several workgroups so the chip is not idle
+  const int items = (Hq + Hkv) * (D / 16) + Hkv * (D / 8);
+  int gy = 1;
+  while (gy < 8 && T * gy < 512 && items > 256 * gy) gy *= 2;
   if (use_rope)
-    hipLaunchKernelGGL((rope_kvwrite_kernel<true>), dim3(T), dim3(256), 0, stream, (bf16*)qkv, (bf16*)kv_cache,
+    hipLaunchKernelGGL((rope_kvwrite_kernel<true>), dim3(T, gy), dim3(256), 0, stream, (bf16*)qkv, partial, splits,
+                       (const bf16*)pbias, T, (bf16*)kv_cache,
                        cos_t, sin_t, tok_pos, tok_seq, block_table, Hq, Hkv, D, max_blocks, num_blocks, rope_len);
   else
-    hipLaunchKernelGGL((rope_kvwrite_kernel<false>), dim3(T), dim3(256), 0, stream, (bf16*)qkv, (bf16*)kv_cache,
+    hipLaunchKernelGGL((rope_kvwrite_kernel<false>), dim3(T, gy), dim3(256), 0, stream, (bf16*)qkv, partial, splits,
+                       (const bf16*)pbias, T, (bf16*)kv_cache,
                        cos_t, sin_t, tok_pos, tok_seq, block_table, Hq, Hkv, D, max_blocks, num_blocks, rope_len);
 }

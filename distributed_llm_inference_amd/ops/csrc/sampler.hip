@@ -12,9 +12,11 @@
 // and the draw uses a counter-based Philox4x32-10 keyed by (seed, step) per row, so a request is
 // reproducible regardless of batching (the reference uses the global unseeded torch RNG).
 //
-// Method: exact radix select (4 x 8 bit) of the k-th largest key, gather of the >= k-th
-// candidates into LDS (at most kCap), bitonic sort of the candidates, block scan for the
-// cumulative mass. Since top-k runs first, top-p only ever touches the <= kCap survivors.
+// Method: a pivot taken from a sorted 1024-element sample puts a few hundred values above it; one
+// pass over the row collects everything >= pivot into LDS (retry with a moved pivot, then an
+// exact 4 x 8-bit radix select, if the count misses [k, kCap]); bitonic sort of the candidates;
+// cut at the k-th value; block scan for the cumulative mass. Since top-k runs first, top-p only
+// ever touches the <= kCap survivors. Rows must be 16-byte aligned (row stride multiple of 4).
 #include "common.h"
 #include "launch.h"
 
@@ -73,7 +75,17 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   if (temp <= 0.f) {
     // greedy: max value, lowest index among ties
     float bv = -__builtin_inff(); int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += kSampThreads) {
+    const int nv4 = V >> 2;
+    const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+    for (int i = tid; i < nv4; i += kSampThreads) {
+      const f32x4 v4 = row4[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = v4[j]; const int ii = i * 4 + j;
+        if (v > bv || (v == bv && ii < bi)) { bv = v; bi = ii; }
+      }
+    }
+    for (int i = (nv4 << 2) + tid; i < V; i += kSampThreads) {
       const float v = row[i];
       if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
     }
@@ -100,8 +112,74 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   if (k <= 0 || k > kCap) k = kCap;
   if (k > V) k = V;
   const float top_p = p.top_p ? p.top_p[r] : 1.f;
+  if (tid == 0) s_ncand = 0u;
 
-  // ---- exact radix select of the k-th largest key -------------------------------------
+  // ---- candidate gathering ----------------------------------------------------------------
+  // Fast path: a pivot from a 1024-element strided sample, chosen so that a few hundred values lie
+  // above it, then ONE pass that collects everything >= pivot into LDS. If at least k and at most
+  // kCap were collected, the exact top-k (ties included) is among them. Only candidates touch the
+  // LDS counter, so there is no atomic contention. A pivot that turns out too high or too low is
+  // moved and the pass repeated; after 4 misses an exact radix select takes over.
+  bool have = false;
+  if (V <= kCap) {
+    if (tid < V) { cval[tid] = row[tid]; cidx[tid] = tid; }
+    if (tid == 0) s_ncand = (unsigned)V;
+    __syncthreads();
+    have = true;
+  } else {
+    const int stride = V / kSampThreads;
+    cval[tid] = row[tid * stride];
+    cidx[tid] = tid;
+    __syncthreads();
+    for (int size = 2; size <= kCap; size <<= 1)            // sort the sample, descending
+      for (int st = size >> 1; st > 0; st >>= 1) {
+        const int partner = tid ^ st;
+        if (partner > tid) {
+          const float x = cval[tid], y = cval[partner];
+          const bool up = (tid & size) == 0;
+          if (up ? x < y : x > y) { cval[tid] = y; cval[partner] = x; }
+        }
+        __syncthreads();
+      }
+    const int target = max(4 * k, 256);
+    int rank = min(kSampThreads - 1, max(1, (int)(((long)target * kSampThreads + V - 1) / V)));
+    if (tid < 16) s_red[tid] = 0.f;
+    __syncthreads();
+    // candidate pivots are read before the buffer is reused for the candidates themselves
+    float piv_hi = cval[max(0, rank / 4)], piv = cval[rank], piv_lo = cval[min(kSampThreads - 1, rank * 4)];
+    float piv_lo2 = cval[min(kSampThreads - 1, rank * 16)];
+    __syncthreads();
+    for (int attempt = 0; attempt < 4 && !have; ++attempt) {
+      if (tid == 0) s_ncand = 0u;
+      __syncthreads();
+      const int nv4 = V >> 2;
+      const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+      for (int i = tid; i < nv4; i += kSampThreads) {
+        const f32x4 v = row4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] >= piv) {
+            const unsigned slot = atomicAdd(&s_ncand, 1u);
+            if (slot < (unsigned)kCap) { cval[slot] = v[j]; cidx[slot] = i * 4 + j; }
+          }
+      }
+      for (int i = (nv4 << 2) + tid; i < V; i += kSampThreads) {
+        const float v = row[i];
+        if (v >= piv) {
+          const unsigned slot = atomicAdd(&s_ncand, 1u);
+          if (slot < (unsigned)kCap) { cval[slot] = v; cidx[slot] = i; }
+        }
+      }
+      __syncthreads();
+      const unsigned n = s_ncand;
+      if (n >= (unsigned)k && n <= (unsigned)kCap) have = true;
+      else if (n > (unsigned)kCap) { piv_lo = piv; piv = piv_hi; piv_hi = __builtin_inff(); }   // too many: raise
+      else { piv_hi = piv; piv = piv_lo; piv_lo = piv_lo2; piv_lo2 = -__builtin_inff(); }        // too few: lower
+      __syncthreads();
+    }
+  }
+  if (!have) {
+  // ---- exact radix select of the k-th largest key (fallback) ----------------------------
   if (tid == 0) { s_prefix = 0u; s_krem = (unsigned)k; s_ncand = 0u; }
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
@@ -139,8 +217,6 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
     __syncthreads();
   }
   const unsigned kth = s_prefix;
-
-  // ---- gather candidates (key >= kth) ---------------------------------------------------
   for (int i = tid; i < V; i += kSampThreads) {
     const float v = row[i];
     if (f2key(v) >= kth) {
@@ -149,7 +225,9 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
     }
   }
   __syncthreads();
-  const int ncand = min((int)s_ncand, kCap);
+  }
+  int ncand = min((int)s_ncand, kCap);
+  __syncthreads();
   if (tid >= ncand) { cval[tid] = -__builtin_inff(); cidx[tid] = 0x7fffffff; }
   __syncthreads();
 
@@ -166,6 +244,19 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
       }
       __syncthreads();
     }
+  }
+
+  // ---- top-k: keep every candidate >= the k-th largest (ties at the k-th value survive) ----
+  {
+    const float kth_val = cval[min(k, ncand) - 1];
+    const bool in_k = tid < ncand && cval[tid] >= kth_val;
+    const unsigned long long bk = __ballot(in_k);
+    if (lane == 0) s_redi[wave] = __popcll(bk);
+    __syncthreads();
+    int nk = 0;
+    for (int w = 0; w < 16; ++w) nk += s_redi[w];
+    __syncthreads();
+    ncand = nk;
   }
 
   // ---- softmax numerators, inclusive scan ----------------------------------------------

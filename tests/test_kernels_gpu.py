@@ -40,7 +40,7 @@ def test_norm(K, H, mode):
     w = bf(torch.randn(H, device=DEV) * 0.1 + 1)
     b = bf(torch.randn(H, device=DEV) * 0.1)
     out = torch.empty_like(x)
-    K.norm(out, x, None, w, b if mode == "layer" else None, None, 1e-5, mode == "layer")
+    K.norm(out, x, None, None, 1, None, w, b if mode == "layer" else None, None, 1e-5, 1 if mode == "layer" else 0)
     want = ref.rmsnorm(x, w, 1e-5) if mode == "rms" else ref.layernorm(x, w, b, 1e-5)
     assert_close(out, want, 2e-2, 1.6e-2, f"norm {mode} H={H}")
 
@@ -53,13 +53,13 @@ def test_norm_fused_add_and_row_gather(K):
     w = bf(torch.rand(H, device=DEV) + 0.5)
     x0 = x.clone()
     out = torch.empty_like(x)
-    K.norm(out, x, d, w, None, None, 1e-5, False)
+    K.norm(out, x, d, None, 1, None, w, None, None, 1e-5, 0)
     h = bf(x0.float() + d.float())
     assert torch.equal(x, h), "residual stream must be updated in place with the rounded sum"
     assert_close(out, ref.rmsnorm(h, w, 1e-5), 2e-2, 1.6e-2, "add_rmsnorm")
     rows = torch.tensor([49, 0, 7], device=DEV, dtype=torch.int32)
     out2 = torch.zeros(3, H, device=DEV, dtype=torch.bfloat16)
-    K.norm(out2, x, None, w, None, rows, 1e-5, False)
+    K.norm(out2, x, None, None, 1, None, w, None, rows, 1e-5, 0)
     assert_close(out2, ref.rmsnorm(x[rows.long()], w, 1e-5), 2e-2, 1.6e-2, "row-gather norm")
 
 
@@ -78,7 +78,7 @@ def test_embed(K):
 
 
 # ------------------------------------------------------------------------------------------
-def _gemm_case(K, M, N, Kd, epi, splitk, out_f32=False, seed=0):
+def _gemm_case(K, M, N, Kd, epi, splitk, out_f32=False, seed=0, ntw=0):
     torch.manual_seed(seed)
     x = bf(torch.randn(M, Kd, device=DEV))
     if epi == 4:
@@ -95,8 +95,8 @@ def _gemm_case(K, M, N, Kd, epi, splitk, out_f32=False, seed=0):
     bias = bf(torch.randn(n_out, device=DEV))
     res = bf(torch.randn(M, n_out, device=DEV))
     out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    ws = torch.empty(16 * 64 * N, device=DEV, dtype=torch.float32) if splitk != 1 else None
-    K.gemm(out, x, wp, bias, res, ws, N, epi, splitk)
+    ws = torch.empty(16 * 128 * N, device=DEV, dtype=torch.float32) if splitk != 1 else None
+    K.gemm(out, x, wp, bias, res, ws, N, epi, splitk, ntw)
     want = ref.gemm(x, w_ref, bias, res, epi)
     assert_close(out, want, 3e-2 if not out_f32 else 2e-3, 2e-2 if not out_f32 else 2e-3,
                  f"gemm M={M} N={N} K={Kd} epi={epi} splitk={splitk}")
@@ -129,11 +129,61 @@ def test_gemm_layout_identity(K):
     x = bf(torch.eye(Kd, device=DEV))[:64]
     w = bf((torch.arange(N, device=DEV).view(-1, 1) * 2 + torch.arange(Kd, device=DEV).view(1, -1) * 3) % 251)
     out = torch.empty(64, N, device=DEV, dtype=torch.float32)
-    K.gemm(out, x, packing.pack_weight(w), None, None, None, N, 0, 1)
+    K.gemm(out, x, packing.pack_weight(w), None, None, None, N, 0, 1, 0)
     assert torch.equal(out, w.float().t()[:64])
 
 
-@pytest.mark.parametrize("M", [65, 128, 300])
+@pytest.mark.parametrize("M", [65, 100, 128])
+@pytest.mark.parametrize("ntw", [1, 2])
+def test_gemm_skinny_128_rows(K, M, ntw):
+    _gemm_case(K, M, 1024, 1024, 3, 1, ntw=ntw)
+    _gemm_case(K, M, 1024, 1024, 0, 4, out_f32=True, ntw=ntw)
+    _gemm_case(K, M, 1024, 512, 4, 2)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 4, 5, 6, 7, 9])
+def test_gemm_skinny_ring_prefetch_edges(K, chunks):
+    """K ranges of 1..9 LDS stages exercise every phase of the 2-deep weight ring (prologue, steady
+    pairs, each peeled tail), for every row-tile count and both n-tile widths, on a grid big enough
+    (N=2048) that waves really run with loads in flight."""
+    for M in (8, 24, 48, 128):
+        for ntw in (1, 2):
+            _gemm_case(K, M, 2048, 128 * chunks, 0, 1, out_f32=True, ntw=ntw)
+    _gemm_case(K, 40, 256, 128 * chunks, 2, 1, ntw=1)
+    _gemm_case(K, 48, 2048, 128 * chunks * 2, 0, 2, out_f32=True, ntw=2)
+
+
+def test_gemm_partials_consumed_by_norm_and_rope(K):
+    """epi 6 writes fp32 split-K partials only; the norm and rope kernels sum them."""
+    torch.manual_seed(9)
+    M, H = 48, 1024
+    x = bf(torch.randn(M, H, device=DEV))
+    w = bf(torch.randn(H, H, device=DEV) / 32)
+    h0 = bf(torch.randn(M, H, device=DEV))
+    bias = bf(torch.randn(H, device=DEV))
+    g = bf(torch.rand(H, device=DEV) + 0.5)
+    for S in (1, 4):
+        ws = torch.full((S * M * H,), float("nan"), device=DEV, dtype=torch.float32)
+        K.gemm(h0, x, packing.pack_weight(w), None, None, ws, H, 6, S, 0)
+        want_sum = ref.gemm(x, w)
+        assert_close(ws.view(S, M, H).sum(0), want_sum, 2e-2, 2e-2, f"partials S={S}")
+        h = h0.clone()
+        out = torch.empty_like(h)
+        K.norm(out, h, None, ws, S, bias, g, None, None, 1e-5, 0)
+        hn = bf(h0.float() + want_sum + bias.float())
+        assert_close(h, hn, 3e-2, 2e-2, "residual folded from partials")
+        assert_close(out, ref.rmsnorm(h, g, 1e-5), 2e-2, 1.6e-2, "norm over folded residual")
+        h2 = h0.clone()
+        K.norm(out, h2, None, ws, S, None, g, None, None, 1e-5, 2)       # fold only
+        assert_close(h2, bf(h0.float() + want_sum), 3e-2, 2e-2, "fold-only")
+        rows = torch.tensor([5, 47], device=DEV, dtype=torch.int32)
+        h3 = h0.clone()
+        o3 = torch.zeros(2, H, device=DEV, dtype=torch.bfloat16)
+        K.norm(o3, h3, None, ws, S, bias, g, None, rows, 1e-5, 0)
+        assert_close(o3, ref.rmsnorm(hn[rows.long()], g, 1e-5), 3e-2, 2e-2, "row-gathered norm over partials")
+
+
+@pytest.mark.parametrize("M", [129, 300])
 @pytest.mark.parametrize("epi", [0, 3, 4, 5])
 def test_gemm_tile(K, M, epi):
     _gemm_case(K, M, 1024, 512, epi, 1)
@@ -144,7 +194,7 @@ def test_gemm_tile_large(K):
 
 
 # ------------------------------------------------------------------------------------------
-def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True):
+def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, qkv_partials=0):
     torch.manual_seed(seed)
     B = len(ctx_lens)
     T = sum(q_lens)
@@ -173,7 +223,7 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True):
             r[:, (Hq + Hkv) * D:] = hist_v[b].reshape(c, -1)
             rows.append(r); tpos += list(range(c)); tseq += [b] * c
         hq = torch.cat(rows)
-        K.rope_kvwrite(hq, kv, cos, sin, torch.tensor(tpos, device=DEV, dtype=torch.int32),
+        K.rope_kvwrite(hq, None, 1, None, kv, cos, sin, torch.tensor(tpos, device=DEV, dtype=torch.int32),
                        torch.tensor(tseq, device=DEV, dtype=torch.int32), block_table, Hq, Hkv, D, use_rope)
     # the new chunk
     qkv = bf(torch.randn(T, qkv_w, device=DEV))
@@ -182,8 +232,18 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True):
     for b, (c, q) in enumerate(zip(ctx_lens, q_lens)):
         tpos += list(range(c, c + q)); tseq += [b] * q; q_start.append(q_start[-1] + q)
     tpos_t = torch.tensor(tpos, device=DEV, dtype=torch.int32)
-    K.rope_kvwrite(qkv, kv, cos, sin, tpos_t, torch.tensor(tseq, device=DEV, dtype=torch.int32), block_table,
-                   Hq, Hkv, D, use_rope)
+    if qkv_partials:
+        # the same values delivered as fp32 split-K partials + bias, the bf16 buffer holding garbage
+        S = qkv_partials
+        pb = bf(torch.randn(qkv_w, device=DEV))
+        parts = torch.randn(S, T, qkv_w, device=DEV)
+        parts[0] = qkv0.float() - pb.float() - parts[1:].sum(0)
+        qkv.fill_(float("nan"))
+        K.rope_kvwrite(qkv, parts.contiguous(), S, pb, kv, cos, sin, tpos_t,
+                       torch.tensor(tseq, device=DEV, dtype=torch.int32), block_table, Hq, Hkv, D, use_rope)
+    else:
+        K.rope_kvwrite(qkv, None, 1, None, kv, cos, sin, tpos_t, torch.tensor(tseq, device=DEV, dtype=torch.int32),
+                       block_table, Hq, Hkv, D, use_rope)
     out = torch.full((T, Hq * D), float("nan"), device=DEV, dtype=torch.bfloat16)
     q_start_t = torch.tensor(q_start, device=DEV, dtype=torch.int32)
     ctx_t = torch.tensor(ctx_lens, device=DEV, dtype=torch.int32)
@@ -221,7 +281,10 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True):
         kd = kd.permute(0, 2, 1, 3).reshape(nb * 32, Hkv, D)[:c + q]
         vd = vd.permute(0, 2, 1, 3).reshape(nb * 32, Hkv, D)[:c + q]
         assert_close(kd, kr, 2e-2, 2e-2, "K cache")
-        assert torch.equal(vd, v_all), "V cache"
+        if qkv_partials:
+            assert_close(vd, v_all, 2e-2, 2e-2, "V cache")
+        else:
+            assert torch.equal(vd, v_all), "V cache"
 
 
 @pytest.mark.parametrize("geom", [(32, 8, 128), (32, 4, 64), (12, 12, 64), (64, 8, 128), (8, 4, 64)])
@@ -244,6 +307,12 @@ def test_attention_prefill_ragged(K, geom):
 
 def test_attention_prefill_chunk_splitkv_norope(K):
     _attn_case(K, 12, 12, 64, ctx_lens=[130, 0], q_lens=[20, 50], splits=2, use_rope=False)
+
+
+@pytest.mark.parametrize("use_rope", [True, False])
+def test_rope_kvwrite_from_split_k_partials(K, use_rope):
+    _attn_case(K, 8, 4, 64, ctx_lens=[3, 40], q_lens=[1, 1], splits=1, qkv_partials=3, use_rope=use_rope)
+    _attn_case(K, 32, 8, 128, ctx_lens=[0, 17], q_lens=[9, 30], splits=1, qkv_partials=2, use_rope=use_rope)
 
 
 def test_attention_softmax_rescale_spike(K):
