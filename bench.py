@@ -9,7 +9,7 @@ random-init weights.
 
 One rank per GPU; rank = pipeline stage; hidden states hop stage to stage over RCCL send/recv,
 sampled token ids hop back from the last stage to stage 0. A "step" is one decode step of EVERY
-in-flight sequence: each of the 2N micro-batches (64 sequences each) goes once through all N
+in-flight sequence: each of the 2N micro-batches (128 sequences each) goes once through all N
 stages — embedding, every decoder layer against the paged KV cache, final norm, lm_head,
 temperature/top-k/top-p sampling, token feedback. Per-GPU work per step is constant in N (2N
 micro-batches x L/N layers), i.e. weak scaling. Prefill of the synthetic prompts and W warm-up
@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="llama-3-8b")
-    ap.add_argument("--batch", type=int, default=64, help="sequences per micro-batch")
+    ap.add_argument("--batch", type=int, default=128, help="sequences per micro-batch")
     ap.add_argument("--micro-batches", type=int, default=0, help="in-flight micro-batches (default 2 x gpus)")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")

@@ -284,7 +284,9 @@ extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_
   const int nblocks = (tiles + 4 * ntw - 1) / (4 * ntw);
   int s = 1;
   if (allow_split) {
-    while (nblocks * s < 256 && s < 16 && chunks / (s * 2) >= 2) s *= 2;
+    // split until ~3/4 of the 256 CUs have a workgroup: a launch of 224 workgroups streams faster
+    // unsplit than as 448 half-length ones that also write twice the partials
+    while (nblocks * s < 192 && s < 16 && chunks / (s * 2) >= 2) s *= 2;
     while (s > 1 && (double)s * M * N * 4.0 > 20.0e6) s /= 2;     // cap the fp32 partial traffic
   }
   (void)epi;
