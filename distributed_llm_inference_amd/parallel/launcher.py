@@ -33,6 +33,7 @@ from ..models.weights import StageWeights, load_stage_weights, random_stage_weig
 from ..runtime.tokenizer import load_tokenizer
 from .pipeline import StageRuntime, stage_main
 from .shm import ST_ERROR, ST_READY, StatusBoard
+from ..utils.tracing import make_tracer
 from .transport import PipelineLinks, make_dist_links, make_loopback_links
 
 
@@ -101,7 +102,10 @@ class LocalPipeline:
         links = make_loopback_links(cfg.pp_size)
         exs = executors or [build_executor(cfg, self.spec, p) for p in self.plans]
         self.executors = exs
-        self.runtimes = [StageRuntime(ex, l, board=self.board, fault=cfg.fault_inject) for ex, l in zip(exs, links)]
+        self.tracer = make_tracer(cfg.trace_path)      # one process: all stages share the tracer
+        self.runtimes = [StageRuntime(ex, l, board=self.board, fault=cfg.fault_inject, tracer=self.tracer,
+                                      trace_path=cfg.trace_path if l.stage == 0 else None)
+                         for ex, l in zip(exs, links)]
         for p in self.plans:
             self.board.register(p.stage, p.layer_start, p.layer_end)
         self.board.set_state(0, ST_READY)
@@ -111,7 +115,8 @@ class LocalPipeline:
             t.start()
             self.threads.append(t)
         self.tokenizer = make_tokenizer(cfg, self.spec)
-        self.engine = Engine(cfg, self.runtimes[0], self.tokenizer, kv_blocks_for(cfg), board=self.board).start()
+        self.engine = Engine(cfg, self.runtimes[0], self.tokenizer, kv_blocks_for(cfg), board=self.board,
+                             tracer=self.tracer).start()
 
     @staticmethod
     def _run_stage(rt):
@@ -124,6 +129,7 @@ class LocalPipeline:
         self.engine.stop()
         for t in self.threads:
             t.join(5.0)
+        self.runtimes[0].dump_trace()
         self.board.close()
 
 
@@ -175,7 +181,8 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
 def _worker_entry(cfg_dict: dict, rank: int, world: int, job: str, master_port: int):
     cfg = EngineConfig.from_dict(cfg_dict)
     spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, master_port)
-    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject)
+    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path),
+                      trace_path=cfg.trace_path)
     try:
         stage_main(rt)
     finally:
@@ -213,10 +220,13 @@ class SpawnedPipeline:
         except BaseException as e:
             self.board.set_state(0, ST_ERROR, f"{type(e).__name__}: {e}")
             raise
-        self.runtime = StageRuntime(ex, self.links, board=self.board, fault=cfg.fault_inject)
+        self.tracer = make_tracer(cfg.trace_path)
+        self.runtime = StageRuntime(ex, self.links, board=self.board, fault=cfg.fault_inject, tracer=self.tracer,
+                                    trace_path=cfg.trace_path)
         self.board.set_state(0, ST_READY)
         self.tokenizer = make_tokenizer(cfg, self.spec)
-        self.engine = Engine(cfg, self.runtime, self.tokenizer, kv_blocks_for(cfg), board=self.board).start()
+        self.engine = Engine(cfg, self.runtime, self.tokenizer, kv_blocks_for(cfg), board=self.board,
+                             tracer=self.tracer).start()
 
     def wait_ready(self, timeout: float = 300.0):
         t0 = time.time()
@@ -235,6 +245,7 @@ class SpawnedPipeline:
             p.join(10.0)
             if p.is_alive():
                 p.terminate()
+        self.runtime.dump_trace()                  # after the joins: folds in the other stages' files
         try:
             import torch.distributed as dist
             if dist.is_initialized():
@@ -259,7 +270,8 @@ def attach_distributed(cfg: EngineConfig):
         # rank 0 creates the board; others attach with retry inside StatusBoard
         pass
     spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, port, local_rank=local_rank)
-    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject)
+    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path),
+                      trace_path=cfg.trace_path)
     return rank, world, rt, board, spec, cfg
 
 

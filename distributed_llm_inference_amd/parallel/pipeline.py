@@ -63,13 +63,15 @@ class FaultInjector:
 
 
 class StageRuntime:
-    def __init__(self, executor, links: PipelineLinks, board=None, fault: str = "", tracer=None):
+    def __init__(self, executor, links: PipelineLinks, board=None, fault: str = "", tracer=None,
+                 trace_path: Optional[str] = None):
         self.ex = executor
         self.links = links
         self.board = board
         self.stage = links.stage
         self.fault = FaultInjector(fault, links.stage)
         self.tracer = tracer
+        self.trace_path = trace_path
         self.device = getattr(executor, "device", torch.device("cpu"))
         self.on_gpu = torch.device(self.device).type == "cuda"
         self.hidden = executor.spec.hidden_size
@@ -158,6 +160,7 @@ class StageRuntime:
         prev_send = self._send_pending.pop(mb, None)
         if prev_send is not None:
             prev_send.wait()          # the output buffer of this micro-batch is free again
+        gtok = self.tracer.gpu_begin() if (self.tracer is not None and self.on_gpu) else None
         if graph:
             out = self.ex.decode_step(desc, x)
         else:
@@ -166,6 +169,9 @@ class StageRuntime:
                 out = self.ex.sample(desc, out)
             elif L.num_stages > 1:
                 out = out.clone()     # eager outputs alias a workspace the next step overwrites
+
+        if gtok is not None:
+            self.tracer.gpu_end(gtok, f"stage{self.stage}.gpu", "compute", {"mb": mb, "tokens": T})
 
         # ---- output ----------------------------------------------------------------------
         result = None
@@ -182,7 +188,7 @@ class StageRuntime:
         if self.board is not None:
             self.board.beat(self.stage, 1, T, time.perf_counter_ns() - t_start)
         if self.tracer is not None:
-            self.tracer.span(f"stage{self.stage}", "step", t_start, time.perf_counter_ns(),
+            self.tracer.span(f"stage{self.stage}.host", "enqueue step", t_start, time.perf_counter_ns(),
                              {"mb": mb, "tokens": T, "decode": desc.is_decode})
         return result
 
@@ -200,6 +206,14 @@ class StageRuntime:
         if self.on_gpu:
             torch.cuda.synchronize(self.device)
         self.barrier_times.append(time.perf_counter())
+
+    def dump_trace(self):
+        """Stage 0 writes `trace_path` and folds in the files the other stages left next to it."""
+        if self.tracer is None or not self.trace_path:
+            return None
+        from ..utils.tracing import stage_trace_path
+        path = stage_trace_path(self.trace_path, self.stage)
+        return self.tracer.dump(path, merge_glob=(self.trace_path + ".stage*") if self.stage == 0 else None)
 
     def drain(self):
         for h in self._send_pending.values():
@@ -243,6 +257,7 @@ def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5) -> int:
     finally:
         try:
             runtime.drain()
+            runtime.dump_trace()
         except Exception:
             pass
     if board is not None:

@@ -281,6 +281,31 @@ def make_loopback_links(num_stages: int) -> List[PipelineLinks]:
     return links
 
 
+def _warm_up_edges(edges, rank: int, backend: str):
+    """One blocking 4-byte message along every edge, in the same global order on every rank.
+
+    RCCL communicators are created lazily by the first send/recv on a group, and that creation
+    blocks the host until the peer makes its matching first call. Inside the serving loop the two
+    ends of the feedback edge reach their first call at unrelated times (stage 0 may pre-post the
+    token receive before anything has gone down the chain), which can turn the lazy creation into
+    a cycle of hosts waiting for each other. Doing it here, chain order then feedback, cannot:
+    every rank's first blocking call is matched by a rank that has already finished its own."""
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    for g, src, dst in edges:
+        if rank == src:
+            dist.send(torch.full((1,), src, dtype=torch.int32, device=dev), dst, group=g)
+        elif rank == dst:
+            t = torch.zeros(1, dtype=torch.int32, device=dev)
+            dist.recv(t, src, group=g)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            if int(t.item()) != src:
+                raise RuntimeError(f"pipeline edge {src}->{dst}: warm-up message corrupted ({int(t.item())})")
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
 def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl: bool = True) -> PipelineLinks:
     """Process groups and control rings for rank `rank` of a `world`-stage pipeline.
 
@@ -289,16 +314,20 @@ def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl:
     edge's group in the same order, then keeps only its own."""
     import torch.distributed as dist
     links = PipelineLinks(rank, world)
+    edges = []
     for s in range(world - 1):
         g = dist.new_group(ranks=[s, s + 1], backend=backend)
+        edges.append((g, s, s + 1))
         if rank == s:
             links.next_data = TorchDistEdge(g, s, s + 1, rank)
         elif rank == s + 1:
             links.prev_data = TorchDistEdge(g, s, s + 1, rank)
     if world > 1:
         g = dist.new_group(ranks=[0, world - 1], backend=backend)     # feedback hop, own communicator
+        edges.append((g, world - 1, 0))
         if rank in (0, world - 1):
             links.fb_data = TorchDistEdge(g, world - 1, 0, rank)
+    _warm_up_edges(edges, rank, backend)
     if use_shm_ctrl:
         # producer creates, consumer attaches (with retry) — no ordering requirement between them
         if rank < world - 1:

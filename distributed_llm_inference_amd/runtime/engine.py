@@ -406,6 +406,9 @@ class Engine:
             req.blocks, req.state = blocks, "prefill"
             mb.rows[row] = req
             mb.fresh.append(req)
+            if self.tracer is not None:
+                self.tracer.instant("scheduler", "admit", {"rid": req.rid, "mb": mb.idx, "row": row,
+                                                           "prompt_tokens": len(req.prompt_ids)})
 
     # ---- step construction -------------------------------------------------------------------
     def _next_step_id(self) -> int:
@@ -555,6 +558,8 @@ class Engine:
     def _finish(self, r: Request, now: float):
         r.state, r.t_done = "finished", now
         self.stats["completed"] += 1
+        if self.tracer is not None:
+            self.tracer.instant("scheduler", "finish", {"rid": r.rid, "tokens": len(r.output)})
         r.done.set()
 
     # ---- introspection -----------------------------------------------------------------------

@@ -39,13 +39,15 @@ def _add_engine_args(ap):
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--debug-top5", action="store_true")
     ap.add_argument("--fault-inject")
+    ap.add_argument("--trace", dest="trace_path", help="write a Chrome-trace JSON of the step timelines here")
 
 
 def config_from_args(a) -> EngineConfig:
     base = EngineConfig.from_yaml(a.config).to_dict() if getattr(a, "config", None) else {}
     base = EngineConfig.from_env(EngineConfig.from_dict(base)).to_dict()
     for k in ("model", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
-              "max_seq_len", "prefill_chunk", "kv_blocks", "max_tokens_cap", "host", "port", "seed", "fault_inject"):
+              "max_seq_len", "prefill_chunk", "kv_blocks", "max_tokens_cap", "host", "port", "seed", "fault_inject",
+              "trace_path"):
         v = getattr(a, k, None)
         if v is not None:
             base[k] = v

@@ -33,6 +33,8 @@ class Tracer:
         self.max_events = max_events
         self._lock = threading.Lock()
         self._pid = os.getpid()
+        self._gpu_base = None
+        self._gpu_spans: List[tuple] = []
 
     def span(self, track: str, name: str, t0_ns: int, t1_ns: int, args: Optional[Dict] = None):
         if len(self.events) >= self.max_events:
@@ -49,9 +51,63 @@ class Tracer:
             if len(self.events) < self.max_events:
                 self.events.append(ev)
 
-    def dump(self, path: str):
+    # ---- device timeline: pairs of HIP events, resolved to host time at dump ------------------
+    def gpu_begin(self):
+        """Records a timing event on the current stream; returns a token for `gpu_end`."""
+        import torch
+        if self._gpu_base is None:
+            base = torch.cuda.Event(enable_timing=True)
+            base.record()
+            base.synchronize()
+            self._gpu_base = (base, time.perf_counter_ns())
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def gpu_end(self, token, track: str, name: str, args: Optional[Dict] = None):
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
         with self._lock:
-            data = {"traceEvents": list(self.events), "displayTimeUnit": "ms"}
+            if len(self._gpu_spans) < self.max_events:
+                self._gpu_spans.append((token, ev, track, name, args or {}))
+
+    def _resolve_gpu(self):
+        if not self._gpu_spans:
+            return
+        base, host_ns = self._gpu_base
+        with self._lock:
+            spans, self._gpu_spans = self._gpu_spans, []
+        for e0, e1, track, name, args in spans:
+            e1.synchronize()
+            t0 = host_ns / 1e3 + base.elapsed_time(e0) * 1e3
+            self.events.append({"name": name, "cat": track, "ph": "X", "pid": self._pid, "tid": track,
+                                "ts": t0, "dur": max(0.0, e0.elapsed_time(e1) * 1e3), "args": args})
+
+    def dump(self, path: str, merge_glob: Optional[str] = None):
+        """Writes the Chrome-trace JSON. `merge_glob`: other stages' dumps to fold in (and delete)."""
+        self._resolve_gpu()
+        with self._lock:
+            events = list(self.events)
+        if merge_glob:
+            import glob
+            for other in sorted(glob.glob(merge_glob)):
+                if os.path.abspath(other) == os.path.abspath(path):
+                    continue
+                try:
+                    with open(other) as f:
+                        events.extend(json.load(f).get("traceEvents", []))
+                    os.unlink(other)
+                except (OSError, ValueError):
+                    pass
         with open(path, "w") as f:
-            json.dump(data, f)
+            json.dump({"traceEvents": events, "displayTimeUnit": "ms"}, f)
         return path
+
+
+def make_tracer(trace_path: Optional[str]) -> Optional[Tracer]:
+    return Tracer() if trace_path else None
+
+
+def stage_trace_path(trace_path: str, stage: int) -> str:
+    return trace_path if stage == 0 else f"{trace_path}.stage{stage}"

@@ -190,3 +190,21 @@ def test_multiprocess_gloo_pipeline_matches_local():
         assert states[1]["state"] == "ready" and states[1]["steps"] > 0 and states[1]["layers"] == "2-4"
     finally:
         pipe.close()
+
+
+def test_trace_file_has_step_and_scheduler_events(tmp_path):
+    """`trace_path` produces one Chrome-trace JSON holding the host timeline of every stage and
+    the scheduler's admit / finish marks."""
+    import json
+    path = str(tmp_path / "trace.json")
+    pipe = LocalPipeline(cfg(pp_size=2, trace_path=path))
+    try:
+        run(pipe, prompts(3), greedy(4))
+    finally:
+        pipe.close()
+    ev = json.load(open(path))["traceEvents"]
+    tracks = {e["cat"] for e in ev}
+    assert {"stage0.host", "stage1.host", "scheduler"} <= tracks
+    names = {e["name"] for e in ev}
+    assert {"enqueue step", "admit", "finish"} <= names
+    assert all(e["dur"] >= 0 for e in ev if e["ph"] == "X")
