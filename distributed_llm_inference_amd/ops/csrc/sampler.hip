@@ -39,8 +39,8 @@ __device__ __forceinline__ void philox_round(unsigned (&c)[4], const unsigned (&
   const unsigned n3 = (unsigned)p0;
   c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
-__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned step, unsigned row) {
-  unsigned c[4] = {step, row, 0u, 0u};
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned step) {
+  unsigned c[4] = {step, 0u, 0u, 0u};
   unsigned k[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   const float kept_total = s_red[0];
 
   // ---- categorical draw -------------------------------------------------------------------
-  const float u = philox_uniform(p.seeds ? p.seeds[r] : 0ull, p.steps ? (unsigned)p.steps[r] : 0u, (unsigned)r);
+  const float u = philox_uniform(p.seeds ? p.seeds[r] : 0ull, p.steps ? (unsigned)p.steps[r] : 0u);
   const float target = u * kept_total;
   const bool below = tid < nkeep && cum <= target;           // entries entirely below the target
   const unsigned long long bb = __ballot(below);

@@ -367,7 +367,9 @@ def test_sampler_greedy_and_determinism(K):
     out, _, _ = _sample(K, logits, [0.0, -1.0, 0.7, 0.7], [50] * 4, [0.9] * 4, [7, 7, 7, 7], [0, 0, 3, 3], V)
     assert out[0] == logits[0].argmax().item() and out[1] == logits[1].argmax().item()
     out2, _, _ = _sample(K, logits, [0.0, -1.0, 0.7, 0.7], [50] * 4, [0.9] * 4, [7, 7, 7, 7], [0, 0, 3, 3], V)
-    assert torch.equal(out, out2), "same (seed, step, row) must give the same draw"
+    assert torch.equal(out, out2), "same (seed, step) must give the same draw"
+    alone, _, _ = _sample(K, logits[2:3].contiguous(), [0.7], [50], [0.9], [7], [3], V)
+    assert alone[0] == out[2], "a draw must not depend on the row the request occupies"
 
 
 def test_sampler_distribution(K):
