@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: decoder-layer weights as e4m3 + per-channel scales (activations, KV, lm_head stay bf16)")
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU (torch backend, gloo)")
     return ap.parse_args()
 
@@ -170,7 +172,7 @@ def main():
     cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
                        use_graphs=not a.no_graph, device="cpu" if a.cpu else "auto",
-                       backend="torch" if a.cpu else "auto", seed=0)
+                       backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype)
     rank, world, rt, board, spec, cfg = attach_distributed(cfg)
     if rank != 0:
         stage_main(rt)
@@ -219,7 +221,7 @@ def main():
             "metric": "output tokens/sec (whole node), Llama-3-8B layer-split PP=N",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": (round(value / base, 1) if base else None), "dtype": "fp32" if a.cpu else "bf16",
+            "vs_baseline": (round(value / base, 1) if base else None), "dtype": "fp32" if a.cpu else ("bf16" if a.dtype == "bf16" else "fp8 weights, bf16 activations"),
             "data": "synthetic prompts (random token ids), random-init weights",
             "p50_token_latency_ms": round(p50, 4),
             "config": {"model": spec.name, "global_batch": global_batch, "seq_len": a.prompt_len,

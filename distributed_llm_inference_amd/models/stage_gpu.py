@@ -59,12 +59,15 @@ class GpuStage:
     def __init__(self, spec: ModelSpec, plan: StagePlan, weights: StageWeights, *, device="cuda",
                  max_slots: int = 256, max_seq_len: int = 2048, num_blocks: Optional[int] = None,
                  max_tokens: int = 2048, max_batch: int = 64, use_graphs: bool = True,
-                 kv_mem_fraction: float = 0.85):
+                 kv_mem_fraction: float = 0.85, weight_dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
         if spec.head_dim not in (64, 128):
             raise ValueError("the HIP attention kernels support head_dim 64 and 128")
+        if weight_dtype not in ("bf16", "fp8"):
+            raise ValueError("weight_dtype must be bf16 or fp8")
         self.K = ops.load()
+        self.w8 = weight_dtype == "fp8"       # decoder-layer GEMM weights as e4m3 + per-channel scale
         self.spec, self.plan = spec, plan
         self.device = torch.device(device)
         self.max_slots, self.max_seq_len = max_slots, max_seq_len
@@ -84,13 +87,13 @@ class GpuStage:
         for i in range(len(weights.layers)):
             l = weights.layers[i]
             p: Dict[str, torch.Tensor] = {"ln1_w": g(l["ln1_w"]), "ln2_w": g(l["ln2_w"])}
-            p["w_qkv"] = packing.pack_weight(g(l["w_qkv"]))
-            p["w_o"] = packing.pack_weight(g(l["w_o"]))
-            p["w_down"] = packing.pack_weight(g(l["w_down"]))
+            self._pack(p, "w_qkv", g(l["w_qkv"]))
+            self._pack(p, "w_o", g(l["w_o"]))
+            self._pack(p, "w_down", g(l["w_down"]))
             if spec.is_llama:
-                p["w_gu"] = packing.pack_weight(packing.interleave_gate_up(g(l["w_gate"]), g(l["w_up"])))
+                self._pack(p, "w_gu", packing.interleave_gate_up(g(l["w_gate"]), g(l["w_up"])))
             else:
-                p["w_fc"] = packing.pack_weight(g(l["w_fc"]))
+                self._pack(p, "w_fc", g(l["w_fc"]))
                 for k in ("ln1_b", "ln2_b", "b_qkv", "b_o", "b_fc", "b_down"):
                     p[k] = g(l[k])
             self.layers.append(p)
@@ -152,6 +155,21 @@ class GpuStage:
         self.scale = 1.0 / math.sqrt(spec.head_dim)
         self.graph_replays = 0
 
+    def _pack(self, p: Dict[str, torch.Tensor], name: str, w: torch.Tensor):
+        """Packs one GEMM weight into MFMA-fragment order; fp8 mode also stores `<name>_s` scales.
+        (The lm_head stays bf16: logits feed a sampler and are the most precision-sensitive GEMM.)"""
+        if self.w8:
+            p[name], p[name + "_s"] = packing.pack_weight_fp8(w)
+        else:
+            p[name] = packing.pack_weight(w)
+
+    def _gemm(self, out, x, p, name, bias, residual, ws, N, epi, splitk, ntw):
+        sc = p.get(name + "_s")
+        if sc is None:
+            self.K.gemm(out, x, p[name], bias, residual, ws, N, epi, splitk, ntw)
+        else:
+            self.K.gemm_w8(out, x, p[name], sc, bias, residual, ws, N, epi, splitk, ntw)
+
     def _workspace_bytes(self) -> int:
         s = self.spec
         per_tok = 2 * (2 * s.hidden_size + s.qkv_size + s.q_size + s.intermediate_size)
@@ -197,19 +215,19 @@ class GpuStage:
             for li, p in enumerate(self.layers):
                 kv = self.kv[li]
                 K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
-                K.gemm(qkv, xn, p["w_qkv"], p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
+                self._gemm(qkv, xn, p, "w_qkv", p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
                 K.rope_kvwrite(qkv, None, 1, None, kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
                                Hq, Hkv, D, llama)
                 K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
                                   self.scale, splits)
-                K.gemm(h, attn, p["w_o"], p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
+                self._gemm(h, attn, p, "w_o", p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
                 K.norm(xn, h, None, None, 1, None, p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
                 if llama:
-                    K.gemm(act, xn, p["w_gu"], None, None, None, 2 * I, 4, 1, 0)
-                    K.gemm(h, act, p["w_down"], None, h, None, H, 2, 1, 0)
+                    self._gemm(act, xn, p, "w_gu", None, None, None, 2 * I, 4, 1, 0)
+                    self._gemm(h, act, p, "w_down", None, h, None, H, 2, 1, 0)
                 else:
-                    K.gemm(act, xn, p["w_fc"], p["b_fc"], None, None, I, 5, 1, 0)
-                    K.gemm(h, act, p["w_down"], p["b_down"], h, None, H, 3, 1, 0)
+                    self._gemm(act, xn, p, "w_fc", p["b_fc"], None, None, I, 5, 1, 0)
+                    self._gemm(h, act, p, "w_down", p["b_down"], h, None, H, 3, 1, 0)
             return None
         # decode regime: weight-streaming GEMMs write fp32 split-K partials which the NEXT kernel
         # (norm / rope) sums while it reads them anyway — no reduce launches, no bf16 round trip
@@ -224,18 +242,18 @@ class GpuStage:
                 K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
             else:
                 K.norm(xn, h, None, ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
-            K.gemm(qkv, xn, p["w_qkv"], None, None, ws, s.qkv_size, 6, sq, nq)
+            self._gemm(qkv, xn, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
             K.rope_kvwrite(qkv, ws, sq, p.get("b_qkv"), kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
                            Hq, Hkv, D, llama)
             K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
                               self.scale, splits)
-            K.gemm(h, attn, p["w_o"], None, None, ws, H, 6, so, no)
+            self._gemm(h, attn, p, "w_o", None, None, ws, H, 6, so, no)
             K.norm(xn, h, None, ws, so, p.get("b_o"), p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
             if llama:
-                K.gemm(act, xn, p["w_gu"], None, None, ws, 2 * I, 4, 0, 0)
+                self._gemm(act, xn, p, "w_gu", None, None, ws, 2 * I, 4, 0, 0)
             else:
-                K.gemm(act, xn, p["w_fc"], p["b_fc"], None, ws, I, 5, 0, 0)
-            K.gemm(h, act, p["w_down"], None, None, ws, H, 6, sd, nd)
+                self._gemm(act, xn, p, "w_fc", p["b_fc"], None, ws, I, 5, 0, 0)
+            self._gemm(h, act, p, "w_down", None, None, ws, H, 6, sd, nd)
             pend = (sd, p.get("b_down"))
         return pend
 

@@ -151,16 +151,26 @@ void rope_kvwrite(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias
 
 // out[M, N_out] = epi(x[M,K] @ W^T); wp = packed weights (uint8 view of the packed image).
 // epi: 0 none, 1 +bias, 2 +residual, 3 +bias+residual, 4 swiglu, 5 +bias -> gelu_tanh.
-void gemm(Tensor out, const Tensor& x, const Tensor& wp, OptTensor bias, OptTensor residual,
-          OptTensor workspace, int64_t N, int64_t epi, int64_t splitk, int64_t ntw) {
+// wscale given: wp holds fp8 e4m3 weights (1 byte each) and wscale one fp32 scale per packed row.
+static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor wscale, OptTensor bias,
+                      OptTensor residual, OptTensor workspace, int64_t N, int64_t epi, int64_t splitk, int64_t ntw) {
   check_bf16(x, "x"); check_rows(x, "x"); check_dev(out, "out"); check_dev(wp, "wp");
   const int64_t M = x.size(0), K = x.size(1);
   DLIA_CHECK(K % 128 == 0, "K must be a multiple of 128");
   DLIA_CHECK(N % 4 == 0, "N must be a multiple of 4");
   DLIA_CHECK(epi >= 0 && epi <= 6, "bad epilogue");
   const int64_t n_pad = (N + 127) / 128 * 128;
-  DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == n_pad * K * 2,
-             "packed weight has ", wp.numel() * wp.element_size(), " bytes, expected ", n_pad * K * 2);
+  const bool w8 = wscale.has_value();
+  const int64_t wbytes = n_pad * K * (w8 ? 1 : 2);
+  DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == wbytes,
+             "packed weight has ", wp.numel() * wp.element_size(), " bytes, expected ", wbytes);
+  const float* wsc = nullptr;
+  if (w8) {
+    check_f32(*wscale, "wscale");
+    DLIA_CHECK(wscale->is_contiguous() && wscale->numel() == n_pad, "wscale must hold one scale per packed row (", n_pad, ")");
+    DLIA_CHECK(reinterpret_cast<uintptr_t>(wscale->data_ptr()) % 16 == 0, "wscale alignment");
+    wsc = wscale->data_ptr<float>();
+  }
   DLIA_CHECK(reinterpret_cast<uintptr_t>(wp.data_ptr()) % 16 == 0, "packed weight alignment");
   const int64_t n_out = epi == 4 ? N / 2 : N;
   if (epi == 4) DLIA_CHECK(N % 32 == 0, "swiglu needs gate/up tile pairs");
@@ -204,13 +214,35 @@ void gemm(Tensor out, const Tensor& x, const Tensor& wp, OptTensor bias, OptTens
       DLIA_CHECK(epi != 6, "partial output needs a workspace");
       sk = 1;
     }
-    dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, ws, nullptr, (int)M, (int)N, (int)K,
+    dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, ws, wsc, (int)M, (int)N, (int)K,
                      x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, nt, stream);
+  } else if (w8) {
+    // prefill over fp8 weights: 128-row slices through the streaming kernel (weights are re-read
+    // per slice at half the bytes of bf16; the widening to bf16 happens in registers)
+    DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 128) feature");
+    const int64_t osz = out.element_size();
+    for (int64_t m0 = 0; m0 < M; m0 += 128) {
+      const int64_t mm = std::min<int64_t>(128, M - m0);
+      const char* rps = rp ? (const char*)rp + m0 * ldr * 2 : nullptr;
+      dlia_gemm_skinny((char*)out.data_ptr() + m0 * out.stride(0) * osz, (const char*)x.data_ptr() + m0 * x.stride(0) * 2,
+                       wp.data_ptr(), bp, rps, nullptr, wsc, (int)mm, (int)N, (int)K, x.stride(0), out.stride(0), ldr,
+                       (int)epi, f32 ? 1 : 0, 1, 2, stream);
+    }
   } else {
     DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 128) feature");
     dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
                    out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
   }
+}
+
+void gemm(Tensor out, const Tensor& x, const Tensor& wp, OptTensor bias, OptTensor residual,
+          OptTensor workspace, int64_t N, int64_t epi, int64_t splitk, int64_t ntw) {
+  gemm_impl(out, x, wp, c10::nullopt, bias, residual, workspace, N, epi, splitk, ntw);
+}
+
+void gemm_w8(Tensor out, const Tensor& x, const Tensor& wp, const Tensor& wscale, OptTensor bias, OptTensor residual,
+             OptTensor workspace, int64_t N, int64_t epi, int64_t splitk, int64_t ntw) {
+  gemm_impl(out, x, wp, wscale, bias, residual, workspace, N, epi, splitk, ntw);
 }
 
 int64_t gemm_splitk(int64_t M, int64_t N, int64_t K) { return dlia_gemm_skinny_splitk((int)M, (int)N, (int)K); }
@@ -305,6 +337,7 @@ TORCH_LIBRARY(dlia, m) {
   m.def("embed(Tensor(a!) out, Tensor ids, Tensor? pos, Tensor wte, Tensor? wpe) -> ()");
   m.def("rope_kvwrite(Tensor(a!) qkv, Tensor? partial, int splits, Tensor? pbias, Tensor(b!) kv_cache, Tensor cos, Tensor sin, Tensor tok_pos, Tensor tok_seq, Tensor block_table, int Hq, int Hkv, int D, bool use_rope) -> ()");
   m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
+  m.def("gemm_w8(Tensor(a!) out, Tensor x, Tensor wp, Tensor wscale, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
   m.def("gemm_config(int M, int N, int K, int epi, bool allow_split) -> int[]");
   m.def("gemm_splitk(int M, int N, int K) -> int");
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
@@ -318,6 +351,7 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
   m.impl("embed", &embed);
   m.impl("rope_kvwrite", &rope_kvwrite);
   m.impl("gemm", &gemm);
+  m.impl("gemm_w8", &gemm_w8);
   m.impl("paged_attention", &paged_attention);
   m.impl("sample", &sample);
   m.impl("advance", &advance);

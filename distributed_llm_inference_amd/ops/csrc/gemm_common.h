@@ -7,7 +7,8 @@ namespace dlia {
 
 struct GemmParams {
   const bf16* x; long ldx;
-  const u32x4* wp;            // packed weights
+  const u32x4* wp;            // packed weights (bf16 fragments, or fp8 e4m3 with two k-steps per 16 B)
+  const float* wscale;        // fp8 weights: per packed row (GEMM column) dequantisation scale; else null
   void* out; long ldo;
   const bf16* bias;           // per output column (pre-activation), may be null
   const bf16* residual; long ldr;

@@ -19,6 +19,12 @@
 //    by whichever kernel consumes the result next (the norm / rope kernels take partial inputs)
 //    or by the reduce kernel below — at a launch boundary, where no fence protocol is needed.
 //
+//  * fp8 weights (W8): the same stream at half the bytes. A 16-B lane load holds OCP e4m3 values
+//    for TWO k-steps (bytes 0-7: k-step 2t, bytes 8-15: k-step 2t+1, same (row, k) lane mapping);
+//    they are widened in registers (v_cvt_pk_f32_fp8 + v_perm: every e4m3 value is exact in bf16)
+//    and fed to the same bf16 MFMA, so activations keep bf16 precision. The per-output-channel
+//    scale is applied to the fp32 accumulators before the epilogue.
+//
 // Replaces the nn.Linear calls inside HF LlamaDecoderLayer that the reference runs on CPU in
 // fp32 over the whole sequence each step (Worker1.py:128-137) and the lm_head
 // (orchestration.py:141).
@@ -57,14 +63,27 @@ __device__ __forceinline__ void wait_vm() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MT, int NTW>
+// 4 e4m3 bytes of `d` -> the low (hi = false) or high (hi = true) pair as packed bf16
+__device__ __forceinline__ unsigned fp8x2_to_bf16x2(unsigned d, bool hi) {
+  const f32x2 f = hi ? __builtin_amdgcn_cvt_pk_f32_fp8(d, true) : __builtin_amdgcn_cvt_pk_f32_fp8(d, false);
+  const float a = f.x, b = f.y;
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);   // upper halves
+}
+__device__ __forceinline__ u32x4 fp8x8_to_bf16x8(unsigned d0, unsigned d1) {
+  return u32x4{fp8x2_to_bf16x2(d0, false), fp8x2_to_bf16x2(d0, true), fp8x2_to_bf16x2(d1, false),
+               fp8x2_to_bf16x2(d1, true)};
+}
+
+template <int MT, int NTW, bool W8>
 __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (MT*16 rows x 256 B)
   constexpr int kStageBytes = MT * 16 * 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
   const int nblk = blockIdx.x, ks = blockIdx.y;
-  const int KT = p.K >> 5;                       // MFMA k-steps in K
+  constexpr int SL = W8 ? 2 : 4;                 // 16-B ring slots per chunk and n-tile
+  constexpr int KPS = 4 / SL;                    // MFMA k-steps held by one slot
+  const int KT = p.K / (32 * KPS);               // slots in K per n-tile
   const int chunks_total = p.K / kSkinnyBK;
   const int cper = (chunks_total + p.splitk - 1) / p.splitk;
   const int c0 = ks * cper;
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
   const u32x4* wbase[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
-    wbase[j] = p.wp + ((long)(wave_active ? tile0 + j : 0) * KT + (long)c0 * 4) * 64 + lane;
+    wbase[j] = p.wp + ((long)(wave_active ? tile0 + j : 0) * KT + (long)c0 * SL) * 64 + lane;
 
   f32x4 acc[MT][NTW];
 #pragma unroll
@@ -100,31 +119,31 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
     // parity par and is refilled with the chunk two ahead right after its last use, so up to
     // 16 KiB of weights per wave stay in flight — also across the per-chunk barrier, which only
     // orders the two LDS stages of x.
-    // Issue order (per chunk c, after the prologue): x(c+2) [MT loads], then per k-step kk the
-    // refill of slot kk [NTW loads]. Hence, in steady state:
-    //   x(c+1) has 4*NTW younger loads when chunk c starts        -> vmcnt(4*NTW)
-    //   slot kk of chunk c has 7*NTW + 2*MT younger loads at its use -> vmcnt(7*NTW + 2*MT)
-    constexpr int kWaitX = 4 * NTW, kWaitW = 7 * NTW + 2 * MT;
+    // Issue order (per chunk c, after the prologue): x(c+2) [MT loads], then per slot s the
+    // refill of slot s [NTW loads]. Hence, in steady state (SL slots per chunk):
+    //   x(c+1) has SL*NTW younger loads when chunk c starts              -> vmcnt(SL*NTW)
+    //   slot s of chunk c has (2*SL-1)*NTW + 2*MT younger loads at its use -> vmcnt of that
+    constexpr int kWaitX = SL * NTW, kWaitW = (2 * SL - 1) * NTW + 2 * MT;
     static_assert(kWaitW <= 63, "vmcnt is a 6-bit counter");
-    u32x4 w[8][NTW], xr[MT];
+    u32x4 w[2 * SL][NTW], xr[MT];
     // prologue, in the same order as the steady state: x(0) | w(0) | x(1) | w(1)
 #pragma unroll
     for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i]);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) gload16_nt(w[kk][j], wbase[j] + (long)kk * 64);
-    // x(0) -> LDS needs only x(0): 4*NTW younger loads
-    wait_vm<4 * NTW>();
+      for (int j = 0; j < NTW; ++j) gload16_nt(w[sl][j], wbase[j] + (long)sl * 64);
+    // x(0) -> LDS needs only x(0): SL*NTW younger loads
+    wait_vm<SL * NTW>();
 #pragma unroll
     for (int i = 0; i < MT; ++i) st16(smem + xdst[i], xr[i]);
     if (n > 1) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i] + kSkinnyBK);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) gload16_nt(w[4 + kk][j], wbase[j] + (long)(4 + kk) * 64);
+        for (int j = 0; j < NTW; ++j) gload16_nt(w[SL + sl][j], wbase[j] + (long)(SL + sl) * 64);
     }
     __syncthreads();
 
@@ -150,18 +169,37 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
       }
       const char* xb = smem + par * kStageBytes;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int sl = 0; sl < SL; ++sl) {
         if constexpr (refill) wait_vm<kWaitW>();
+        u32x4 wf[KPS][NTW];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int r = i * 16 + l15;
-          const u32x4 xf = *reinterpret_cast<const u32x4*>(xb + r * 256 + (((kk * 4 + quad) ^ l15) << 4));
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(w[par * 4 + kk][j], xf, acc[i][j]);
+        for (int j = 0; j < NTW; ++j) {
+          const u32x4 raw = w[par * SL + sl][j];
+          if constexpr (W8) {
+            wf[0][j] = fp8x8_to_bf16x8(raw[0], raw[1]);
+            wf[KPS - 1][j] = fp8x8_to_bf16x8(raw[2], raw[3]);
+          } else {
+            wf[0][j] = raw;
+          }
         }
-        if constexpr (refill) {
+        if constexpr (refill && W8) {             // the raw slot is free once widened
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) gload16_nt(w[par * 4 + kk][j], wbase[j] + (long)((c + 2) * 4 + kk) * 64);
+          for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < KPS; ++ks2) {
+          const int kk = sl * KPS + ks2;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int r = i * 16 + l15;
+            const u32x4 xf = *reinterpret_cast<const u32x4*>(xb + r * 256 + (((kk * 4 + quad) ^ l15) << 4));
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(wf[ks2][j], xf, acc[i][j]);
+          }
+        }
+        if constexpr (refill && !W8) {
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
         }
       }
       __syncthreads();
@@ -185,6 +223,14 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
   if (!wave_active) return;
 
   // acc[i][j][r] = C[m = i*16 + l15][n = (tile0+j)*16 + quad*4 + r]
+  if constexpr (W8) {
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + (tile0 + j) * 16 + quad * 4);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] *= sc;
+    }
+  }
   if (p.partial_only || p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -258,7 +304,8 @@ static void launch_skinny(const GemmParams& p, hipStream_t stream) {
   const int nblocks = (p.ntiles + 4 * NTW - 1) / (4 * NTW);
   dim3 grid(nblocks, p.splitk), block(kSkinnyThreads);
   const size_t smem = 2 * MT * 16 * 256;
-  hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW>), grid, block, smem, stream, p);
+  if (p.wscale) hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, true>), grid, block, smem, stream, p);
+  else          hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, false>), grid, block, smem, stream, p);
 }
 
 template <int MT>
@@ -302,13 +349,12 @@ extern "C" int dlia_gemm_skinny_splitk(int M, int N, int K) {
 // epi: 0..5 as documented in launch.h; 6 = write fp32 partials [splitk][M][N] only (the consumer
 // kernel sums them). splitk / ntw <= 0 pick the heuristic.
 extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const void* bias,
-                                 const void* residual, float* workspace, unsigned* counters,
+                                 const void* residual, float* workspace, const float* wscale,
                                  int M, int N, int K, long ldx, long ldo, long ldr, int epi,
                                  int out_f32, int splitk, int ntw, hipStream_t stream) {
-  (void)counters;
   if (M <= 0 || N <= 0) return;
   GemmParams p;
-  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.out = out; p.ldo = ldo;
+  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = wscale; p.out = out; p.ldo = ldo;
   p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;
   p.residual = (epi == 2 || epi == 3) ? (const bf16*)residual : nullptr;
   p.ldr = ldr; p.partial = workspace; p.M = M; p.N = N; p.K = K;

@@ -36,7 +36,7 @@ void dlia_rope_kvwrite(void* qkv, const float* partial, int splits, const void* 
 // N = 2*N_out), 5 +bias then gelu_tanh, 6 fp32 partials [splitk][M][N] only (summed by the
 // consumer kernel). out_f32: write fp32 instead of bf16.
 void dlia_gemm_skinny(void* out, const void* x, const void* wp, const void* bias,
-                      const void* residual, float* workspace, unsigned* counters,
+                      const void* residual, float* workspace, const float* wscale,
                       int M, int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32,
                       int splitk, int ntw, hipStream_t stream);
 // the decomposition the launcher would choose: n-tiles per wave and split-K factor

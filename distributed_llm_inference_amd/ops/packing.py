@@ -38,6 +38,48 @@ def unpack_weight(wp: torch.Tensor, N: int, K: int) -> torch.Tensor:
     return v.reshape(Np, K)[:N].contiguous()
 
 
+FP8_MAX = 448.0   # largest finite OCP e4m3 value
+
+
+def quantize_fp8(w: torch.Tensor):
+    """[N, K] -> (e4m3 values as uint8 [N, K], fp32 scale [N]) with w ~= q * scale[:, None].
+    Per-output-channel symmetric scaling: the row's absolute maximum maps to the e4m3 maximum."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-12)
+    scale = amax / FP8_MAX
+    q = (wf / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def dequantize_fp8(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+def pack_weight_fp8(w: torch.Tensor):
+    """[N, K] -> (packed uint8 image of padded_n(N)*K bytes, fp32 scales [padded_n(N)]).
+
+    Same lane mapping as `pack_weight`, but a lane's 16 bytes hold TWO k-steps: block
+    (n-tile nt, k-pair kp) = 64 lanes x 16 B where lane l = quad*16 + n holds
+    W[nt*16 + n][kp*64 + quad*8 .. +8] in bytes 0-7 and W[..][kp*64 + 32 + quad*8 .. +8] in 8-15."""
+    N, K = w.shape
+    if K % PACK_K:
+        raise ValueError(f"K={K} must be a multiple of {PACK_K}")
+    q, scale = quantize_fp8(w)
+    Np = padded_n(N)
+    if Np != N:
+        q = torch.cat([q, q.new_zeros(Np - N, K)], dim=0)
+        scale = torch.cat([scale, scale.new_ones(Np - N)])
+    v = q.reshape(Np // 16, 16, K // 64, 2, 4, 8)        # [nt, n, kp, half, quad, j]
+    return v.permute(0, 2, 4, 1, 3, 5).contiguous().reshape(-1), scale.contiguous()
+
+
+def unpack_weight_fp8(wp: torch.Tensor, scale: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """Dequantised [N, K] fp32 view of a `pack_weight_fp8` image (tests)."""
+    Np = padded_n(N)
+    v = wp.reshape(Np // 16, K // 64, 4, 16, 2, 8).permute(0, 3, 1, 4, 2, 5).reshape(Np, K)
+    return dequantize_fp8(v, scale)[:N].contiguous()
+
+
 def interleave_gate_up(w_gate: torch.Tensor, w_up: torch.Tensor) -> torch.Tensor:
     """[I,H],[I,H] -> [2I,H] whose 16-row tiles alternate gate, up: the wave that owns tiles
     (2t, 2t+1) then holds gate and up of the same 16 output columns in identical fragment

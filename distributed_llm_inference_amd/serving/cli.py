@@ -20,6 +20,7 @@ from ..config import EngineConfig
 def _add_engine_args(ap):
     ap.add_argument("--config", help="YAML file with EngineConfig fields")
     ap.add_argument("--model")
+    ap.add_argument("--dtype", choices=["bf16", "fp8", "fp32"], help="fp8 = e4m3 layer weights with per-channel scales")
     ap.add_argument("--pp-size", type=int)
     ap.add_argument("--partition", choices=["balanced", "even", "explicit"])
     ap.add_argument("--layer-ranges", help='explicit ranges, e.g. "0-11,11-22"')
@@ -45,7 +46,7 @@ def _add_engine_args(ap):
 def config_from_args(a) -> EngineConfig:
     base = EngineConfig.from_yaml(a.config).to_dict() if getattr(a, "config", None) else {}
     base = EngineConfig.from_env(EngineConfig.from_dict(base)).to_dict()
-    for k in ("model", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
+    for k in ("model", "dtype", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
               "max_seq_len", "prefill_chunk", "kv_blocks", "max_tokens_cap", "host", "port", "seed", "fault_inject",
               "trace_path"):
         v = getattr(a, k, None)

@@ -122,6 +122,72 @@ def test_gemm_skinny_swiglu_splitk_and_vocab_pad(K):
     _gemm_case(K, 3, 1000, 256, 0, 1, out_f32=True)
 
 
+def _gemm_w8_case(K, M, N, Kd, epi, splitk, out_f32=False, seed=0, ntw=0):
+    """fp8 (e4m3, per-channel scale) weights against the fp32 product with the DEQUANTISED weights:
+    the kernel widens e4m3 -> bf16 exactly, so only the usual bf16 activation rounding remains."""
+    torch.manual_seed(seed)
+    x = bf(torch.randn(M, Kd, device=DEV))
+    if epi == 4:
+        wg = torch.randn(N // 2, Kd, device=DEV) / math.sqrt(Kd)
+        wu = torch.randn(N // 2, Kd, device=DEV) / math.sqrt(Kd)
+        wp, sc = packing.pack_weight_fp8(packing.interleave_gate_up(wg, wu))
+        w_ref = torch.cat([packing.dequantize_fp8(*packing.quantize_fp8(wg)), packing.dequantize_fp8(*packing.quantize_fp8(wu))], 0)
+        n_out = N // 2
+    else:
+        w = torch.randn(N, Kd, device=DEV) / math.sqrt(Kd) * (1 + torch.arange(N, device=DEV).view(-1, 1) % 7)
+        wp, sc = packing.pack_weight_fp8(w)
+        w_ref = packing.dequantize_fp8(*packing.quantize_fp8(w))
+        n_out = N
+    bias = bf(torch.randn(n_out, device=DEV))
+    res = bf(torch.randn(M, n_out, device=DEV))
+    ws = torch.full((16 * 128 * N,), float("nan"), device=DEV, dtype=torch.float32) if (splitk != 1 or epi == 6) else None
+    if epi == 6:
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        K.gemm_w8(out, x, wp, sc, None, None, ws, N, 6, splitk, ntw)
+        S = splitk if splitk > 0 else int(K.gemm_config(M, N, Kd, 6, True)[1])
+        got = ws[:S * M * N].view(S, M, N).sum(0)
+        assert_close(got, x.float() @ w_ref.t(), 2e-3, 2e-3, f"w8 partials M={M} N={N} K={Kd} S={S}")
+        return
+    out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    K.gemm_w8(out, x, wp, sc, bias, res, ws, N, epi, splitk, ntw)
+    want = ref.gemm(x, w_ref, bias, res, epi)
+    assert_close(out, want, 3e-2 if not out_f32 else 2e-3, 2e-2 if not out_f32 else 2e-3,
+                 f"gemm_w8 M={M} N={N} K={Kd} epi={epi} splitk={splitk}")
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 64, 128])
+@pytest.mark.parametrize("epi", [0, 3, 4, 5, 6])
+def test_gemm_w8_epilogues(K, M, epi):
+    _gemm_w8_case(K, M, 512, 256, epi, 1, out_f32=(epi == 0))
+    _gemm_w8_case(K, M, 2048, 1024, epi, 0 if epi != 6 else 4)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 4, 5, 6, 7, 9])
+def test_gemm_w8_ring_prefetch_edges(K, chunks):
+    for M in (8, 48, 128):
+        for ntw in (1, 2):
+            _gemm_w8_case(K, M, 2048, 128 * chunks, 0, 1, out_f32=True, ntw=ntw)
+
+
+def test_gemm_w8_prefill_slices(K):
+    """More than 128 rows over fp8 weights: 128-row slices through the streaming kernel."""
+    _gemm_w8_case(K, 300, 1024, 512, 3, 1)
+    _gemm_w8_case(K, 257, 1024, 512, 4, 1)
+
+
+def test_fp8_quantisation_error_is_bounded(K):
+    """e4m3 with per-row scaling: relative error of a weight is at most 2^-4 of its row maximum
+    bucket; the matmul error stays within a few percent of the output scale."""
+    torch.manual_seed(1)
+    w = torch.randn(512, 1024, device=DEV) / 32
+    deq = packing.dequantize_fp8(*packing.quantize_fp8(w))
+    rel = ((deq - w).abs() / w.abs().clamp_min(1e-3 * w.abs().max())).max().item()
+    assert rel < 0.0726        # half an ulp of a 3-bit mantissa = 2^-4, plus subnormal slack
+    x = bf(torch.randn(32, 1024, device=DEV))
+    a, b = x.float() @ w.t(), x.float() @ deq.t()
+    assert (a - b).abs().max().item() < 0.06 * a.abs().max().item()
+
+
 def test_gemm_layout_identity(K):
     """A = I with an ASYMMETRIC B: catches a transposed accumulator map that random-vs-random
     tolerance checks could hide."""

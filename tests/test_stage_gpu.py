@@ -121,3 +121,36 @@ def test_graph_decode_split_stage_hidden_handoff():
         hid = s0.decode_step(b, x=t2)
         t2 = s1.decode_step(b, x=hid).clone()
         assert torch.equal(tf, t2), f"step {i}"
+
+
+def test_fp8_weight_stage_tracks_bf16_stage():
+    """fp8 (e4m3 + per-channel scale) layer weights: logits stay close to the bf16-weight stage,
+    prefill (sliced streaming GEMMs over > 128 rows), eager decode and graph decode."""
+    from distributed_llm_inference_amd.models.stage_gpu import GpuStage
+    spec = gpu_spec("llama")
+    plan = make_plans(spec, 1)[0]
+    mk = lambda wd: GpuStage(spec, plan, random_stage_weights(spec, plan, seed=5, dtype=torch.bfloat16), max_slots=8,
+                             max_seq_len=256, num_blocks=64, max_tokens=256, max_batch=8, weight_dtype=wd)
+    a, b = mk("bf16"), mk("fp8")
+    assert b.memory_report()["weights_gib"] < 0.75 * a.memory_report()["weights_gib"]
+    g = torch.Generator().manual_seed(0)
+    lens = [150, 20]                      # 170 tokens: the > 128-row path
+    toks = torch.randint(3, spec.vocab_size, (sum(lens),), generator=g).tolist()
+    tables = {0: list(range(0, 8)), 1: list(range(8, 16))}
+    d = step([0, 1], lens, [0, 0], toks, tables=tables)
+    def near(x, y, what):              # quantisation noise: a few percent of the logit scale
+        x, y = x.float().cpu(), y.float().cpu()
+        err, scale = (x - y).abs().max().item(), y.abs().max().item()
+        assert err <= 0.15 * scale, f"{what}: max err {err:.4f} vs scale {scale:.4f}"
+        cos = torch.nn.functional.cosine_similarity(x.flatten(), y.flatten(), dim=0).item()
+        assert cos > 0.98, f"{what}: cosine {cos:.4f}"
+
+    la, lb = a.forward(d, torch.tensor(toks)).clone(), b.forward(d, torch.tensor(toks)).clone()
+    near(lb, la, "fp8 prefill logits")
+    ctx = list(lens)
+    for i in range(4):
+        t = [int(x) for x in la.argmax(-1).tolist()]
+        d = step([0, 1], [1, 1], ctx, t)
+        la, lb = a.forward(d, torch.tensor(t)).clone(), b.forward(d, torch.tensor(t)).clone()
+        near(lb, la, f"fp8 decode logits step {i}")
+        ctx = [c + 1 for c in ctx]
