@@ -1,0 +1,70 @@
+"""Closed-loop serving benchmark of the whole engine in one process: R requests with random prompt
+lengths arrive at once, the scheduler batches them continuously (chunked prefill + decode
+micro-batches), and the script reports request throughput, output tokens/s, TTFT and TPOT.
+Unlike bench.py (steady-state decode steps only) this includes prefill, admission, retirement and
+the host-side scheduler."""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_llm_inference_amd.config import EngineConfig
+from distributed_llm_inference_amd.parallel.launcher import make_pipeline
+from distributed_llm_inference_amd.runtime.sampler import SamplingParams
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--requests", type=int, default=512)
+    ap.add_argument("--prompt-min", type=int, default=32)
+    ap.add_argument("--prompt-max", type=int, default=256)
+    ap.add_argument("--new-tokens", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--micro-batches", type=int, default=2)
+    ap.add_argument("--pp-size", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--cpu", action="store_true")
+    a = ap.parse_args()
+    cfg = EngineConfig(model=a.model, pp_size=a.pp_size, max_batch=a.batch, num_micro_batches=a.micro_batches,
+                       max_seq_len=((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=2048, dtype=a.dtype,
+                       device="cpu" if a.cpu else "auto", backend="torch" if a.cpu else "auto",
+                       transport="loopback" if a.cpu else "auto")
+    pipe = make_pipeline(cfg)
+    eng = pipe.engine
+    g = torch.Generator().manual_seed(0)
+    V = eng.spec.vocab_size
+    prompts = [torch.randint(10, V - 10, (int(torch.randint(a.prompt_min, a.prompt_max + 1, (1,), generator=g)),),
+                             generator=g).tolist() for _ in range(a.requests)]
+    sp = SamplingParams(temperature=0.7, top_k=50, top_p=0.9, max_new_tokens=a.new_tokens, stop_on_eos=False)
+    try:
+        warm = [eng.submit(p, SamplingParams(0.7, 50, 0.9, 4, stop_on_eos=False)) for p in prompts[:a.batch]]
+        for r in warm:
+            r.wait(600)
+        t0 = time.perf_counter()
+        reqs = [eng.submit(p, sp) for p in prompts]
+        for r in reqs:
+            r.wait(1800)
+        dt = time.perf_counter() - t0
+    finally:
+        snap = eng.snapshot()
+        pipe.close()
+    out_tokens = sum(len(r.output) for r in reqs)
+    ttft = sorted((r.t_first - r.t_arrival) * 1e3 for r in reqs if r.t_first)
+    tpot = sorted(((r.t_done - r.t_first) / max(1, len(r.output) - 1)) * 1e3 for r in reqs if r.t_first and r.t_done)
+    q = lambda v, p: v[min(len(v) - 1, int(p * len(v)))] if v else None
+    print(json.dumps({"model": eng.spec.name, "requests": a.requests, "seconds": round(dt, 3),
+                      "prompt_tokens": sum(len(p) for p in prompts), "output_tokens": out_tokens,
+                      "output_tok_per_s": round(out_tokens / dt, 1), "requests_per_s": round(a.requests / dt, 2),
+                      "ttft_ms_p50": q(ttft, 0.5), "ttft_ms_p99": q(ttft, 0.99), "tpot_ms_p50": q(tpot, 0.5),
+                      "tpot_ms_p99": q(tpot, 0.99), "recompositions": snap.get("recompositions"),
+                      "config": {"max_batch": a.batch, "micro_batches": a.micro_batches, "pp": a.pp_size, "dtype": a.dtype}}))
+
+
+if __name__ == "__main__":
+    main()
