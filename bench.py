@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--decode-streams", type=int, default=2,
+                    help="HIP streams the decode micro-batches of a stage alternate over")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: decoder-layer weights as e4m3 + per-channel scales (activations, KV, lm_head stay bf16)")
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU (torch backend, gloo)")
@@ -115,7 +117,12 @@ class Driver:
             else:
                 d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, None, replay=True)
                 fbw = self.fb[mb]
-            toks = self.rt.execute(d, fbw)
+            with self.rt.stream_scope(d):
+                toks = self.rt.execute(d, fbw)
+                if self.links.num_stages == 1 and self.on_gpu and record:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.lat_events[mb].append(ev)
             n = self.rt.result_count(d)
             if self.links.num_stages > 1:
                 buf = self.rt.fb_buffer(mb, n)
@@ -132,13 +139,8 @@ class Driver:
                     if record:
                         self.fb[mb].wait()
                         self.lat_events[mb].append(time.perf_counter())
-            else:
-                if self.on_gpu and record:
-                    ev = torch.cuda.Event(enable_timing=True)
-                    ev.record()
-                    self.lat_events[mb].append(ev)
-                elif record:
-                    self.lat_events[mb].append(time.perf_counter())
+            elif record and not self.on_gpu:
+                self.lat_events[mb].append(time.perf_counter())
 
     def barrier(self):
         self.rt.execute(control(KIND_BARRIER))
@@ -172,7 +174,7 @@ def main():
     cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
                        use_graphs=not a.no_graph, device="cpu" if a.cpu else "auto",
-                       backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype)
+                       backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype, decode_streams=a.decode_streams)
     rank, world, rt, board, spec, cfg = attach_distributed(cfg)
     if rank != 0:
         stage_main(rt)
@@ -227,7 +229,7 @@ def main():
             "config": {"model": spec.name, "global_batch": global_batch, "seq_len": a.prompt_len,
                        "parallelism": f"pp{world}", "micro_batches": cfg.num_micro_batches,
                        "micro_batch_size": cfg.max_batch, "layer_ranges": plans,
-                       "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": cfg.use_graphs,
+                       "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": cfg.use_graphs, "decode_streams": cfg.decode_streams,
                        "backend": rt.ex.backend}}), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -35,6 +35,22 @@ BLOCK = packing.KV_BLOCK
 
 
 @dataclass
+class _Work:
+    """Activation workspaces of one step in flight. The eager path owns one (sized for a prefill
+    chunk); every decode micro-batch owns its own (sized for the micro-batch), so that the graphs
+    of different micro-batches can run concurrently on different streams."""
+    h: torch.Tensor              # bf16 [T, H]   residual stream
+    xn: torch.Tensor             # bf16 [T, H]   normalised input of the next GEMM
+    qkv: torch.Tensor            # bf16 [T, (Hq + 2 Hkv) D]
+    attn: torch.Tensor           # bf16 [T, Hq D]
+    act: torch.Tensor            # bf16 [T, I]
+    ws: torch.Tensor             # fp32 split-K partials [S, M, N], reused by every GEMM of the step
+    attn_ws: torch.Tensor        # fp32 split-KV partials
+    head_x: Optional[torch.Tensor]   # bf16 [B, H]      (last stage)
+    logits: Optional[torch.Tensor]   # fp32 [B, vocab_pad]
+
+
+@dataclass
 class _MicroBatchState:
     """Static device buffers (and the captured graph) of one in-flight decode micro-batch."""
     B: int
@@ -49,6 +65,7 @@ class _MicroBatchState:
     top_p: torch.Tensor
     seeds: torch.Tensor
     steps: torch.Tensor          # int32 [B] RNG counters; advanced in-graph
+    wk: Optional[_Work] = None
     graph: Optional[torch.cuda.CUDAGraph] = None
     splits: int = 1
 
@@ -122,30 +139,20 @@ class GpuStage:
         self.block_table = torch.full((max_slots + 1, self.max_blocks), -1, device=dev, dtype=torch.int32)
 
         # ---- activation workspaces ----------------------------------------------------------
-        MT = self.max_tokens
-        z = lambda *s, dt=bf: torch.zeros(*s, device=dev, dtype=dt)
-        self.h = z(MT, H)
-        self.xn = z(MT, H)
-        self.qkv = z(MT, spec.qkv_size)
-        self.attn = z(MT, spec.q_size)
-        self.act = z(MT, I)
-        # split-K partial workspace [S, M, N]: one buffer, reused by every GEMM of a step (each
-        # partial is consumed by the next kernel before the next GEMM writes)
+        self.max_splits = 16
+        # split-K partial workspace [S, M, N]: one buffer per step in flight, reused by every GEMM
+        # of the step (each partial is consumed by the next kernel before the next GEMM writes)
         need = 1
         for (n_, k_, e_) in ((spec.qkv_size, H, 6), (H, spec.q_size, 6), (H, I, 6),
                              (2 * I if spec.is_llama else I, H, 4 if spec.is_llama else 5),
                              (packing.padded_n(V), H, 0)):
             for m_ in range(1, 129):        # any token count up to 128 takes the weight-streaming path
                 need = max(need, int(self.K.gemm_config(m_, n_, k_, e_, True)[1]) * m_ * n_)
-        self.ws = z(need, dt=torch.float32)
-        self.max_splits = 16
-        self.attn_ws = z(int(self.K.attention_ws_floats(max_batch, 1, spec.num_heads, spec.num_kv_heads,
-                                                        spec.head_dim, self.max_splits)), dt=torch.float32)
-        if plan.has_head:
-            self.head_x = z(max_batch, H)
-            self.logits = z(max_batch, self.vocab_pad, dt=torch.float32)
+        self._ws_floats = need
+        self.wk0 = self._new_work(self.max_tokens)
         # eager-path metadata (device) + pinned staging
         i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
+        MT = self.max_tokens
         self.md_tok_pos, self.md_tok_seq = i32(MT), i32(MT)
         self.md_q_start, self.md_ctx, self.md_slots = i32(max_batch + 1), i32(max_batch), i32(max_batch)
         self.md_rows, self.md_ids = i32(max_batch), i32(MT)
@@ -154,6 +161,18 @@ class GpuStage:
         self._ones = torch.ones(H, device=dev, dtype=bf)
         self.scale = 1.0 / math.sqrt(spec.head_dim)
         self.graph_replays = 0
+
+    def _new_work(self, rows: int) -> _Work:
+        s, dev, bf = self.spec, self.device, torch.bfloat16
+        z = lambda *shape, dt=bf: torch.zeros(*shape, device=dev, dtype=dt)
+        B = self.max_batch
+        return _Work(
+            h=z(rows, s.hidden_size), xn=z(rows, s.hidden_size), qkv=z(rows, s.qkv_size), attn=z(rows, s.q_size),
+            act=z(rows, s.intermediate_size), ws=z(self._ws_floats, dt=torch.float32),
+            attn_ws=z(int(self.K.attention_ws_floats(B, 1, s.num_heads, s.num_kv_heads, s.head_dim, self.max_splits)),
+                      dt=torch.float32),
+            head_x=z(B, s.hidden_size) if self.plan.has_head else None,
+            logits=z(B, self.vocab_pad, dt=torch.float32) if self.plan.has_head else None)
 
     def _pack(self, p: Dict[str, torch.Tensor], name: str, w: torch.Tensor):
         """Packs one GEMM weight into MFMA-fragment order; fp8 mode also stores `<name>_s` scales.
@@ -200,14 +219,14 @@ class GpuStage:
             self._gemm_cfg[key] = c
         return c
 
-    def _layers(self, T: int, B: int, tok_pos, tok_seq, q_start, ctx, slots, max_q: int, splits: int):
-        """Runs this stage's decoder layers on self.h[:T]. Returns the pending split-K partial
+    def _layers(self, wk: _Work, T: int, B: int, tok_pos, tok_seq, q_start, ctx, slots, max_q: int, splits: int):
+        """Runs this stage's decoder layers on wk.h[:T]. Returns the pending split-K partial
         (splits, bias) of the last down projection that the caller still has to fold into h
         (decode regime), or None when h is final."""
         K, s = self.K, self.spec
-        h, xn, qkv, attn, act = self.h[:T], self.xn[:T], self.qkv[:T], self.attn[:T], self.act[:T]
+        h, xn, qkv, attn, act = wk.h[:T], wk.xn[:T], wk.qkv[:T], wk.attn[:T], wk.act[:T]
         Hq, Hkv, D, H, I = s.num_heads, s.num_kv_heads, s.head_dim, s.hidden_size, s.intermediate_size
-        partial = self.attn_ws if splits > 1 else None
+        partial = wk.attn_ws if splits > 1 else None
         llama = s.is_llama
         nmode = 0 if llama else 1
         if T > 128:
@@ -231,7 +250,7 @@ class GpuStage:
             return None
         # decode regime: weight-streaming GEMMs write fp32 split-K partials which the NEXT kernel
         # (norm / rope) sums while it reads them anyway — no reduce launches, no bf16 round trip
-        ws = self.ws
+        ws = wk.ws
         nq, sq = self._cfg(T, s.qkv_size, H, 6)
         no, so = self._cfg(T, H, s.q_size, 6)
         nd, sd = self._cfg(T, H, I, 6)
@@ -257,26 +276,26 @@ class GpuStage:
             pend = (sd, p.get("b_down"))
         return pend
 
-    def _fold(self, T: int, pend):
+    def _fold(self, wk: _Work, T: int, pend):
         """h[:T] += pending partials (stage output that is sent on rather than normalised here)."""
         if pend is not None:
-            self.K.norm(self.xn[:T], self.h[:T], None, self.ws, pend[0], pend[1], self._ones, None, None,
+            self.K.norm(wk.xn[:T], wk.h[:T], None, wk.ws, pend[0], pend[1], self._ones, None, None,
                         self.spec.norm_eps, 2)
 
-    def _head(self, rows_idx: torch.Tensor, R: int, T: int, pend):
-        """Final norm on the selected rows of self.h (folding the pending partials of those rows
-        first), then lm_head -> self.logits[:R]."""
+    def _head(self, wk: _Work, rows_idx: torch.Tensor, R: int, T: int, pend):
+        """Final norm on the selected rows of wk.h (folding the pending partials of those rows
+        first), then lm_head -> wk.logits[:R]."""
         s, K = self.spec, self.K
-        hx = self.head_x[:R]
+        hx = wk.head_x[:R]
         nmode = 0 if s.is_llama else 1
         if pend is None:
-            K.norm(hx, self.h[:T], None, None, 1, None, self.final_norm_w, self.final_norm_b, rows_idx[:R],
+            K.norm(hx, wk.h[:T], None, None, 1, None, self.final_norm_w, self.final_norm_b, rows_idx[:R],
                    s.norm_eps, nmode)
         else:
-            K.norm(hx, self.h[:T], None, self.ws, pend[0], pend[1], self.final_norm_w, self.final_norm_b,
+            K.norm(hx, wk.h[:T], None, wk.ws, pend[0], pend[1], self.final_norm_w, self.final_norm_b,
                    rows_idx[:R], s.norm_eps, nmode)
-        K.gemm(self.logits[:R], hx, self.lm_head, None, None, self.ws, self.vocab_pad, 0, 0, 0)
-        return self.logits[:R]
+        K.gemm(wk.logits[:R], hx, self.lm_head, None, None, wk.ws, self.vocab_pad, 0, 0, 0)
+        return wk.logits[:R]
 
     # ---- generic (eager) forward: prefill chunks, and decode when graphs are off ---------
     @torch.no_grad()
@@ -287,6 +306,7 @@ class GpuStage:
             raise ValueError(f"step with {B} sequences / {T} tokens exceeds the stage limits "
                              f"({self.max_batch} / {self.max_tokens})")
         self.set_tables(batch)
+        wk = self.wk0
         tok_pos, tok_seq, q_start, rows = [], [], [0], []
         for slot, q, c, smp in zip(batch.slots, batch.q_lens, batch.ctx_lens, batch.sample):
             if c + q > self.max_seq_len:
@@ -304,24 +324,24 @@ class GpuStage:
             ids = x.to(device=dev, dtype=torch.int32).reshape(-1)
             if ids.numel() != T:
                 raise ValueError(f"expected {T} token ids, got {ids.numel()}")
-            self.K.embed(self.h[:T], ids, self.md_tok_pos[:T], self.embed, self.pos_embed)
+            self.K.embed(wk.h[:T], ids, self.md_tok_pos[:T], self.embed, self.pos_embed)
         else:
             if tuple(x.shape) != (T, s.hidden_size):
                 raise ValueError(f"expected hidden [{T},{s.hidden_size}], got {tuple(x.shape)}")
-            self.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16))
+            wk.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16))
         max_q = max(batch.q_lens) if batch.q_lens else 1
-        pend = self._layers(T, B, self.md_tok_pos[:T], self.md_tok_seq[:T], self.md_q_start[:B + 1], self.md_ctx[:B],
+        pend = self._layers(wk, T, B, self.md_tok_pos[:T], self.md_tok_seq[:T], self.md_q_start[:B + 1], self.md_ctx[:B],
                             self.md_slots[:B], max_q, 1)
         if not self.plan.has_head:
-            self._fold(T, pend)
-            return self.h[:T]
+            self._fold(wk, T, pend)
+            return wk.h[:T]
         R = len(rows)
         if R == 0:
-            return self.logits[:0, :s.vocab_size]
+            return wk.logits[:0, :s.vocab_size]
         if R > self.max_batch:
             raise ValueError(f"{R} sampled rows exceed max_batch {self.max_batch}")
         up(self.md_rows, rows)
-        return self._head(self.md_rows, R, T, pend)[:, :s.vocab_size]
+        return self._head(wk, self.md_rows, R, T, pend)[:, :s.vocab_size]
 
     @torch.no_grad()
     def sample(self, batch: StepBatch, logits: torch.Tensor) -> torch.Tensor:
@@ -333,7 +353,7 @@ class GpuStage:
         if R == 0:
             return out
         t = lambda vals, dt: torch.tensor(vals, dtype=dt).to(dev)
-        lg = self.logits[:R]      # `logits` is a view of this buffer (padded columns ignored by `vocab`)
+        lg = self.wk0.logits[:R]  # `logits` is a view of this buffer (padded columns ignored by `vocab`)
         self.K.sample(out, lg, t([batch.temperature[i] for i in idx], torch.float32),
                       t([batch.top_k[i] for i in idx], torch.int32), t([batch.top_p[i] for i in idx], torch.float32),
                       t([batch.seeds[i] for i in idx], torch.int64), t([batch.sample_steps[i] for i in idx], torch.int32),
@@ -353,28 +373,28 @@ class GpuStage:
             hidden_out=None if self.plan.has_head else torch.zeros(B, H, device=dev, dtype=torch.bfloat16),
             tokens=i32() if self.plan.has_head else None,
             temperature=torch.zeros(B, device=dev), top_k=i32(), top_p=torch.ones(B, device=dev),
-            seeds=torch.zeros(B, device=dev, dtype=torch.int64), steps=i32())
+            seeds=torch.zeros(B, device=dev, dtype=torch.int64), steps=i32(), wk=self._new_work(B))
         self._mbs[mb] = st
         return st
 
     def _decode_body(self, st: _MicroBatchState):
         """One decode step over the micro-batch's static buffers (captured into the graph)."""
-        K, B = self.K, st.B
+        K, B, wk = self.K, st.B, st.wk
         if self.plan.has_embed:
-            K.embed(self.h[:B], st.ids, st.ctx, self.embed, self.pos_embed)
+            K.embed(wk.h[:B], st.ids, st.ctx, self.embed, self.pos_embed)
         else:
-            self.h[:B].copy_(st.hidden_in)
-        pend = self._layers(B, B, st.ctx, st.slots, self._arange[:B + 1], st.ctx, st.slots, 1, st.splits)
+            wk.h[:B].copy_(st.hidden_in)
+        pend = self._layers(wk, B, B, st.ctx, st.slots, self._arange[:B + 1], st.ctx, st.slots, 1, st.splits)
         if self.plan.has_head:
-            self._head(self._arange, B, B, pend)
-            K.sample(st.tokens, self.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
+            self._head(wk, self._arange, B, B, pend)
+            K.sample(st.tokens, wk.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
                      self.spec.vocab_size, None, None)
             K.advance(st.steps, 1)
             if self.plan.has_embed:
                 st.ids.copy_(st.tokens)      # single-stage pipeline: the feedback hop is local
         else:
-            self._fold(B, pend)
-            st.hidden_out.copy_(self.h[:B])
+            self._fold(wk, B, pend)
+            st.hidden_out.copy_(wk.h[:B])
         K.advance(st.ctx, 1)
 
     @torch.no_grad()

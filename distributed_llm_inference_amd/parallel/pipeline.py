@@ -20,6 +20,7 @@ and the orchestrator's relay loop (orchestration.py:109-137) with a true stage->
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import time
 import traceback
@@ -64,7 +65,7 @@ class FaultInjector:
 
 class StageRuntime:
     def __init__(self, executor, links: PipelineLinks, board=None, fault: str = "", tracer=None,
-                 trace_path: Optional[str] = None):
+                 trace_path: Optional[str] = None, decode_streams: int = 2):
         self.ex = executor
         self.links = links
         self.board = board
@@ -82,6 +83,14 @@ class StageRuntime:
         self._local_fb: Dict[int, torch.Tensor] = {}   # single-stage pipeline: last tokens per micro-batch
         self.steps = 0
         self.barrier_times: List[float] = []
+        # Decode micro-batches own their workspaces, so consecutive micro-batches go to different
+        # HIP streams: the ramp-up and tail of one micro-batch's kernels (and its recv/send) overlap
+        # the other's instead of leaving the chip part-idle at every kernel boundary. Eager steps
+        # (prefill) share one workspace and stay on the main stream.
+        self._main_stream = torch.cuda.current_stream(self.device) if self.on_gpu else None
+        n = max(1, int(decode_streams)) if self.on_gpu and hasattr(executor, "decode_step") else 0
+        self._decode_streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        self._eager_done = None           # event after the latest eager step (orders later decode steps)
 
     # ---- helpers ---------------------------------------------------------------------------
     def _graph_decode(self, desc: StepBatch) -> bool:
@@ -105,14 +114,47 @@ class StageRuntime:
             self._fb_bufs[key] = b
         return b
 
+    # ---- streams ----------------------------------------------------------------------------
+    def _stream_of(self, desc: StepBatch):
+        if not self._decode_streams or desc.kind != KIND_STEP or not self._graph_decode(desc):
+            return self._main_stream
+        return self._decode_streams[desc.micro_batch % len(self._decode_streams)]
+
+    def stream_scope(self, desc: StepBatch):
+        """Context in which `execute(desc)` enqueues its device work; callers that post-process the
+        result (copy tokens to the host, record events) do it inside the same scope."""
+        s = self._stream_of(desc)
+        return torch.cuda.stream(s) if s is not None else contextlib.nullcontext()
+
     # ---- one descriptor ----------------------------------------------------------------------
     def execute(self, desc: StepBatch, fb_wait: Optional[Handle] = None) -> Optional[torch.Tensor]:
         """Runs this stage's share of `desc`. Returns sampled tokens (int32 tensor, device) when
         this is the last stage, else None. `fb_wait`: completion of the feedback receive that
         filled the stage-0 token buffer for this step."""
+        if desc.kind != KIND_STEP or not self.on_gpu:
+            return self._execute(desc, fb_wait)
+        s = self._stream_of(desc)
+        with torch.cuda.stream(s):
+            if s is self._main_stream:
+                # eager step: after the decode steps already queued for this micro-batch
+                for ds in self._decode_streams:
+                    s.wait_stream(ds)
+                out = self._execute(desc, fb_wait)
+                self._eager_done = torch.cuda.Event()
+                self._eager_done.record(s)
+            else:
+                if self._eager_done is not None:
+                    s.wait_event(self._eager_done)        # prefill of these sequences has run
+                out = self._execute(desc, fb_wait)
+        return out
+
+    def _execute(self, desc: StepBatch, fb_wait: Optional[Handle] = None) -> Optional[torch.Tensor]:
         L = self.links
         if desc.kind != KIND_STEP:
             if desc.kind == KIND_RELEASE:
+                if self.on_gpu:
+                    for ds in self._decode_streams:       # steps still reading these rows finish first
+                        torch.cuda.current_stream(self.device).wait_stream(ds)
                 self.ex.release(desc.slots)
             if L.next_ctrl is not None:
                 L.next_ctrl.put(desc.to_bytes())

@@ -97,13 +97,18 @@ class Edge:
 # ---------------------------------------------------------------------------------------------
 class LoopbackEdge(Edge):
     def __init__(self):
-        self.q: "queue.Queue[torch.Tensor]" = queue.Queue()
+        self.q: "queue.Queue" = queue.Queue()      # (tensor, ready event or None)
         self._order_lock = threading.Lock()
         self._next_ticket = 0
         self._served = 0
 
     def send(self, t):
-        self.q.put(t.detach().clone())
+        c = t.detach().clone()
+        ev = None
+        if c.is_cuda:                      # the receiver may run on another stream: hand it an event
+            ev = torch.cuda.Event()
+            ev.record()
+        self.q.put((c, ev))
         return Handle()
 
     def recv(self, buf, timeout: float = 60.0):
@@ -129,13 +134,11 @@ class _LoopbackRecv(Handle):
             if e._served != self.ticket:
                 return False
             try:
-                t = e.q.get(block=False)
+                t, ev = e.q.get(block=False)
             except queue.Empty:
-                if not block:
-                    return False
-                t = None
-            if t is None:
                 return False
+            if ev is not None:
+                torch.cuda.current_stream(t.device).wait_event(ev)
             if t.numel() != self.buf.numel():
                 raise RuntimeError(f"loopback edge: expected {self.buf.numel()} elements, got {t.numel()}")
             self.buf.copy_(t.reshape(self.buf.shape).to(self.buf.dtype))

@@ -479,45 +479,46 @@ class Engine:
         self.stats["steps"] += 1
         n_res = self.rt.result_count(d)
         fb_wait = mb.last_fb if d.token_ids is None else None
-        if self.on_gpu and getattr(mb, "last_copy", None) is not None:
-            # the previous step's tokens must have left the static buffer before it is rewritten
-            torch.cuda.current_stream().wait_event(mb.last_copy)
-        tokens = self.rt.execute(d, fb_wait)
-        res = None
-        if self.links.num_stages == 1:
-            if self.on_gpu:
-                host = torch.empty(n_res, dtype=torch.int32).pin_memory() if n_res else torch.empty(0, dtype=torch.int32)
-                ev = torch.cuda.Event()
-                done = torch.cuda.Event()
-                done.record()
-                with torch.cuda.stream(self._res_stream):
-                    self._res_stream.wait_event(done)
-                    if n_res:
-                        host.copy_(tokens, non_blocking=True)
-                    ev.record()
-                mb.last_copy = ev
-                res = _Result(d, rows, event=ev, host=host)
+        with self.rt.stream_scope(d):      # the stream this step runs on (one per decode micro-batch)
+            if self.on_gpu and getattr(mb, "last_copy", None) is not None:
+                # the previous step's tokens must have left the static buffer before it is rewritten
+                torch.cuda.current_stream().wait_event(mb.last_copy)
+            tokens = self.rt.execute(d, fb_wait)
+            res = None
+            if self.links.num_stages == 1:
+                if self.on_gpu:
+                    host = torch.empty(n_res, dtype=torch.int32).pin_memory() if n_res else torch.empty(0, dtype=torch.int32)
+                    ev = torch.cuda.Event()
+                    done = torch.cuda.Event()
+                    done.record()
+                    with torch.cuda.stream(self._res_stream):
+                        self._res_stream.wait_event(done)
+                        if n_res:
+                            host.copy_(tokens, non_blocking=True)
+                        ev.record()
+                    mb.last_copy = ev
+                    res = _Result(d, rows, event=ev, host=host)
+                else:
+                    res = _Result(d, rows, tokens=tokens)
             else:
-                res = _Result(d, rows, tokens=tokens)
-        else:
-            buf = self.rt.fb_buffer(mb.idx, n_res)
-            if self.on_gpu:
-                host = torch.empty(n_res, dtype=torch.int32).pin_memory()
-                ev, got = torch.cuda.Event(), torch.cuda.Event()
-                with torch.cuda.stream(self._res_stream):
+                buf = self.rt.fb_buffer(mb.idx, n_res)
+                if self.on_gpu:
+                    host = torch.empty(n_res, dtype=torch.int32).pin_memory()
+                    ev, got = torch.cuda.Event(), torch.cuda.Event()
+                    with torch.cuda.stream(self._res_stream):
+                        h = self.links.fb_data.recv(buf) if n_res else None
+                        if h is not None:
+                            h.wait()
+                        got.record()
+                        if n_res:
+                            host.copy_(buf, non_blocking=True)
+                        ev.record()
+                    mb.last_fb = _EventHandle(got)
+                    res = _Result(d, rows, event=ev, host=host)
+                else:
                     h = self.links.fb_data.recv(buf) if n_res else None
-                    if h is not None:
-                        h.wait()
-                    got.record()
-                    if n_res:
-                        host.copy_(buf, non_blocking=True)
-                    ev.record()
-                mb.last_fb = _EventHandle(got)
-                res = _Result(d, rows, event=ev, host=host)
-            else:
-                h = self.links.fb_data.recv(buf) if n_res else None
-                mb.last_fb = h
-                res = _Result(d, rows, tokens=buf, handle=h)
+                    mb.last_fb = h
+                    res = _Result(d, rows, tokens=buf, handle=h)
         mb.inflight.append(res)
 
     # ---- results -------------------------------------------------------------------------------
