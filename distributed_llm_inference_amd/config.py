@@ -38,7 +38,7 @@ class EngineConfig:
     kv_mem_fraction: float = 0.85
     use_graphs: bool = True                # hipGraph-captured decode
     max_inflight_steps: int = 2            # steps of one micro-batch issued ahead of their results
-    decode_streams: int = 2                # HIP streams the decode micro-batches of a stage alternate over
+    decode_streams: int = 3                # HIP streams the decode micro-batches of a stage alternate over
     # ---- sampling defaults (reference values) -----------------------------------------
     temperature: float = 0.7               # orchestration.py:341
     top_k: int = 50                        # orchestration.py:353

@@ -32,6 +32,7 @@ from .spec import ModelSpec
 from .weights import StageWeights
 
 BLOCK = packing.KV_BLOCK
+DECODE_ROWS = 256      # row count up to which GEMMs take the weight-streaming kernel (with split-K partials)
 
 
 @dataclass
@@ -146,7 +147,7 @@ class GpuStage:
         for (n_, k_, e_) in ((spec.qkv_size, H, 6), (H, spec.q_size, 6), (H, I, 6),
                              (2 * I if spec.is_llama else I, H, 4 if spec.is_llama else 5),
                              (packing.padded_n(V), H, 0)):
-            for m_ in range(1, 129):        # any token count up to 128 takes the weight-streaming path
+            for m_ in range(1, DECODE_ROWS + 1):    # any token count up to this takes the weight-streaming path
                 need = max(need, int(self.K.gemm_config(m_, n_, k_, e_, True)[1]) * m_ * n_)
         self._ws_floats = need
         self.wk0 = self._new_work(self.max_tokens)
@@ -229,7 +230,7 @@ class GpuStage:
         partial = wk.attn_ws if splits > 1 else None
         llama = s.is_llama
         nmode = 0 if llama else 1
-        if T > 128:
+        if T > DECODE_ROWS:
             # prefill regime: tiled MFMA GEMMs with fused bias / residual / activation epilogues
             for li, p in enumerate(self.layers):
                 kv = self.kv[li]

@@ -192,7 +192,7 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
     rp = residual->data_ptr(); ldr = residual->stride(0);
   }
   auto stream = cur_stream();
-  if (M <= 128) {
+  if (M <= 256) {
     float* ws = nullptr;
     int sk = (int)splitk, nt = (int)ntw;
     if (sk <= 0 || nt <= 0) {
@@ -217,19 +217,19 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
     dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, ws, wsc, (int)M, (int)N, (int)K,
                      x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, nt, stream);
   } else if (w8) {
-    // prefill over fp8 weights: 128-row slices through the streaming kernel (weights are re-read
+    // prefill over fp8 weights: 256-row slices through the streaming kernel (weights are re-read
     // per slice at half the bytes of bf16; the widening to bf16 happens in registers)
-    DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 128) feature");
+    DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
     const int64_t osz = out.element_size();
-    for (int64_t m0 = 0; m0 < M; m0 += 128) {
-      const int64_t mm = std::min<int64_t>(128, M - m0);
+    for (int64_t m0 = 0; m0 < M; m0 += 256) {
+      const int64_t mm = std::min<int64_t>(256, M - m0);
       const char* rps = rp ? (const char*)rp + m0 * ldr * 2 : nullptr;
       dlia_gemm_skinny((char*)out.data_ptr() + m0 * out.stride(0) * osz, (const char*)x.data_ptr() + m0 * x.stride(0) * 2,
                        wp.data_ptr(), bp, rps, nullptr, wsc, (int)mm, (int)N, (int)K, x.stride(0), out.stride(0), ldr,
                        (int)epi, f32 ? 1 : 0, 1, 2, stream);
     }
   } else {
-    DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 128) feature");
+    DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
     dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
                    out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
   }

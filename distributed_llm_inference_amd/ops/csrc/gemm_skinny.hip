@@ -1,4 +1,4 @@
-// Weight-streaming GEMM for the decode regime: out[M,N] = epi(x[M,K] @ W[N,K]^T), M <= 64.
+// Weight-streaming GEMM for the decode regime: out[M,N] = epi(x[M,K] @ W[N,K]^T), M <= 256.
 //
 // Regime: every weight byte is read once per step and M is tiny, so the kernel is a
 // HBM-streaming loop whose only job is to keep ~32+ KiB of loads in flight per CU.
@@ -28,6 +28,7 @@
 // Replaces the nn.Linear calls inside HF LlamaDecoderLayer that the reference runs on CPU in
 // fp32 over the whole sequence each step (Worker1.py:128-137) and the lm_head
 // (orchestration.py:141).
+#include <cstdlib>
 #include "common.h"
 #include "gemm_common.h"
 #include "launch.h"
@@ -56,6 +57,15 @@ __device__ __forceinline__ void gload16(u32x4& dst, const void* p) {
 }
 __device__ __forceinline__ void gload16_nt(u32x4& dst, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
+}
+// 16 B per lane, global -> LDS without a VGPR round trip: lane l lands at lds_addr + 16 l. M0
+// carries the (wave-uniform) LDS address and is restored, since the compiler does not expect
+// inline asm to change it. Counts in vmcnt like any other load.
+__device__ __forceinline__ void gload_lds16(const void* gptr, unsigned lds_addr) {
+  unsigned saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+               "s_nop 0\n\ts_mov_b32 m0, %0"
+               : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -92,17 +102,32 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
   const int tile0 = (nblk * 4 + wave) * NTW;     // first n-tile of this wave
   const bool wave_active = tile0 < p.ntiles;     // (ntiles is a multiple of 8 by packing)
 
-  // x staging map: thread -> (row = tid/16 + 16 i, 16-B slot = tid%16), slot XOR-swizzled by row&15
+  // x staging map: thread -> (row = tid/16 + 16 i, 16-B slot = tid%16), slot XOR-swizzled by row&15.
+  // Row r = srow + 16 i has r & 15 == srow & 15, so the LDS destination of piece i is a constant
+  // 4 KiB step from piece 0 (an immediate offset) and only one source pointer is kept; rows past
+  // M re-read the last row (never stored to the output).
   const int srow = tid >> 4, sslot = tid & 15;
-  const bf16* xsrc[MT];
-  int xdst[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  const bf16* xbase = p.x + sslot * 8 + (long)c0 * kSkinnyBK;
+  const int xdst0 = srow * 256 + ((sslot ^ (srow & 15)) << 4);
+  auto xsrc = [&](int i, int c) -> const bf16* {
     const int r = srow + 16 * i;
-    const int rc = r < p.M ? r : p.M - 1;        // rows past M re-read the last row; never stored
-    xsrc[i] = p.x + (long)rc * p.ldx + sslot * 8 + (long)c0 * kSkinnyBK;
-    xdst[i] = r * 256 + ((sslot ^ (r & 15)) << 4);
-  }
+    return xbase + (long)(r < p.M ? r : p.M - 1) * p.ldx + (long)c * kSkinnyBK;
+  };
+  // 256-row variant (MT == 16): the register file cannot also hold a chunk of x, so x goes
+  // global -> LDS by DMA. Wave instruction Q = wave*MT + q fills rows 4Q..4Q+3 (1 KiB); the LDS image
+  // must be lane-linear, so the XOR swizzle is applied to the SOURCE column instead.
+  constexpr bool XDMA = MT >= 16;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  auto xdma = [&](int stage, int c) {
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+      const int row = 4 * (wv * MT + q) + quad;
+      const bf16* src = p.x + (long)(row < p.M ? row : p.M - 1) * p.ldx + ((l15 ^ (row & 15)) << 3) +
+                        (long)(c0 + c) * kSkinnyBK;
+      gload_lds16(src, lds0 + stage * kStageBytes + (wv * MT + q) * 1024);
+    }
+  };
   const u32x4* wbase[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
@@ -126,24 +151,45 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
     constexpr int kWaitX = SL * NTW, kWaitW = (2 * SL - 1) * NTW + 2 * MT;
     static_assert(kWaitW <= 63, "vmcnt is a 6-bit counter");
     u32x4 w[2 * SL][NTW], xr[MT];
-    // prologue, in the same order as the steady state: x(0) | w(0) | x(1) | w(1)
+    if constexpr (!XDMA) {
+      // prologue, in the same order as the steady state: x(0) | w(0) | x(1) | w(1)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i]);
-#pragma unroll
-    for (int sl = 0; sl < SL; ++sl)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) gload16_nt(w[sl][j], wbase[j] + (long)sl * 64);
-    // x(0) -> LDS needs only x(0): SL*NTW younger loads
-    wait_vm<SL * NTW>();
-#pragma unroll
-    for (int i = 0; i < MT; ++i) st16(smem + xdst[i], xr[i]);
-    if (n > 1) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i] + kSkinnyBK);
+      for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc(i, 0));
 #pragma unroll
       for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) gload16_nt(w[SL + sl][j], wbase[j] + (long)(SL + sl) * 64);
+        for (int j = 0; j < NTW; ++j) gload16_nt(w[sl][j], wbase[j] + (long)sl * 64);
+      // x(0) -> LDS needs only x(0): SL*NTW younger loads
+      wait_vm<SL * NTW>();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) st16(smem + xdst0 + i * 4096, xr[i]);
+      if (n > 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc(i, 1));
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) gload16_nt(w[SL + sl][j], wbase[j] + (long)(SL + sl) * 64);
+      }
+    } else {
+      // DMA variant: chunk c issues x(c+1) (into the LDS stage chunk c-1 just released) and then
+      // the refills w(c+2); the global issue order is w(0) x(0) w(1) | x(1) w(2) | x(2) w(3) ...,
+      // which gives the same two wait counts as above with "x(c+1) landed" checked at the END of
+      // chunk c, before the barrier that lets chunk c+1 read it.
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) gload16_nt(w[sl][j], wbase[j] + (long)sl * 64);
+      xdma(0, 0);
+      if (n > 1) {
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) gload16_nt(w[SL + sl][j], wbase[j] + (long)(SL + sl) * 64);
+        wait_vm<SL * NTW>();                       // x(0) in LDS; w(1) may still fly
+      } else {
+        wait_vm<0>();
+      }
     }
     __syncthreads();
 
@@ -152,19 +198,28 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
     auto body = [&](auto PAR, auto REFILL, int c) {
       constexpr int par = decltype(PAR)::value;
       constexpr bool refill = decltype(REFILL)::value != 0;
-      if constexpr (refill) {
+      if constexpr (XDMA) {
+        if constexpr (refill) {
+          xdma(par ^ 1, c + 1);
+        } else if (c + 1 < n) {
+          xdma(par ^ 1, c + 1);
+          wait_vm<MT>();                           // everything but the DMA just issued
+        } else {
+          wait_vm<0>();
+        }
+      } else if constexpr (refill) {
         char* xn = smem + (par ^ 1) * kStageBytes;
         wait_vm<kWaitX>();
 #pragma unroll
-        for (int i = 0; i < MT; ++i) st16(xn + xdst[i], xr[i]);
+        for (int i = 0; i < MT; ++i) st16(xn + xdst0 + i * 4096, xr[i]);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc[i] + (long)(c + 2) * kSkinnyBK);
+        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc(i, c + 2));
       } else {
         wait_vm<0>();
         if (c + 1 < n) {
           char* xn = smem + (par ^ 1) * kStageBytes;
 #pragma unroll
-          for (int i = 0; i < MT; ++i) st16(xn + xdst[i], xr[i]);
+          for (int i = 0; i < MT; ++i) st16(xn + xdst0 + i * 4096, xr[i]);
         }
       }
       const char* xb = smem + par * kStageBytes;
@@ -201,6 +256,10 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
 #pragma unroll
           for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
         }
+      }
+      if constexpr (XDMA) {                        // x(c+1) must be in LDS before anyone passes the barrier
+        if constexpr (refill) wait_vm<kWaitX>();
+        else wait_vm<0>();
       }
       __syncthreads();
     };
@@ -299,11 +358,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   epilogue4(p, m, n, g, u);
 }
 
+constexpr bool smem_needs_opt_in(int mt) { return 2 * mt * 16 * 256 > 64 * 1024; }
+
 template <int MT, int NTW>
 static void launch_skinny(const GemmParams& p, hipStream_t stream) {
   const int nblocks = (p.ntiles + 4 * NTW - 1) / (4 * NTW);
   dim3 grid(nblocks, p.splitk), block(kSkinnyThreads);
   const size_t smem = 2 * MT * 16 * 256;
+  if constexpr (smem_needs_opt_in(MT)) {          // more than 64 KiB of dynamic LDS is opt-in, once per kernel
+    static const bool once = [] {
+      const int bytes = 2 * MT * 16 * 256;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NTW, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NTW, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      return true;
+    }();
+    (void)once;
+  }
   if (p.wscale) hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, true>), grid, block, smem, stream, p);
   else          hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, false>), grid, block, smem, stream, p);
 }
@@ -333,8 +405,17 @@ extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_
   if (allow_split) {
     // split until ~3/4 of the 256 CUs have a workgroup: a launch of 224 workgroups streams faster
     // unsplit than as 448 half-length ones that also write twice the partials
-    while (nblocks * s < 192 && s < 16 && chunks / (s * 2) >= 2) s *= 2;
-    while (s > 1 && (double)s * M * N * 4.0 > 20.0e6) s /= 2;     // cap the fp32 partial traffic
+    static const int forced = [] {                // tuning override: workgroups a launch should reach
+      const char* e = getenv("DLIA_GEMM_TARGET_WGS");
+      return e ? atoi(e) : 0;
+    }();
+    // Large micro-batches run two at a time on two streams (the other stream fills the idle CUs),
+    // and their partials are big: split less. Measured with bench.py at 128 rows: 96 beats 192 by 2.5 %.
+    // Beyond 128 rows the kernel is MFMA/LDS-bound with one wave per SIMD: more, shorter workgroups win again.
+    const int target = forced > 0 ? forced : (M > 64 && M <= 128 ? 96 : 192);
+    while (nblocks * s < target && s < 16 && chunks / (s * 2) >= 2) s *= 2;
+    const double cap = M > 128 ? 36.0e6 : 20.0e6;                  // cap the fp32 partial traffic
+    while (s > 1 && (double)s * M * N * 4.0 > cap) s /= 2;
   }
   (void)epi;
   *ntw_out = ntw; *splitk_out = s;
@@ -374,7 +455,8 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
   if (M <= 16)      launch_skinny_ntw<1>(p, ntw, stream);
   else if (M <= 32) launch_skinny_ntw<2>(p, ntw, stream);
   else if (M <= 64) launch_skinny_ntw<4>(p, ntw, stream);
-  else              launch_skinny_ntw<8>(p, ntw, stream);
+  else if (M <= 128) launch_skinny_ntw<8>(p, ntw, stream);
+  else               launch_skinny_ntw<16>(p, ntw, stream);
   if (splitk > 1 && !p.partial_only) {
     const int nout = p.act == 1 ? N / 2 : N;
     const long work = (long)M * (nout / 4);

@@ -48,6 +48,14 @@ def lint_asm(text: str, kernel_regex: str = r".") -> List[Tuple[str, str]]:
                     n = int(m.group(1))
                     pending = pending[len(pending) - n:] if 0 < n < len(pending) else ([] if n == 0 else pending)
                 continue
+            if op.startswith("global_load_lds"):
+                # LDS-DMA: every operand is a source, nothing lands in a register; it still takes
+                # a place in the in-order vmcnt queue
+                src = set().union(*[_regs(t) for t in toks]) if toks else set()
+                if any(p & src for p in pending):
+                    bad.append((name, o))
+                pending.append(set())
+                continue
             if op.startswith(("global_load", "buffer_load", "flat_load")):
                 src = set().union(*[_regs(t) for t in toks[1:]]) if len(toks) > 1 else set()
                 if any(p & src for p in pending):

@@ -65,7 +65,7 @@ class FaultInjector:
 
 class StageRuntime:
     def __init__(self, executor, links: PipelineLinks, board=None, fault: str = "", tracer=None,
-                 trace_path: Optional[str] = None, decode_streams: int = 2):
+                 trace_path: Optional[str] = None, decode_streams: int = 3):
         self.ex = executor
         self.links = links
         self.board = board

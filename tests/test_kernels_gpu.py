@@ -95,7 +95,7 @@ def _gemm_case(K, M, N, Kd, epi, splitk, out_f32=False, seed=0, ntw=0):
     bias = bf(torch.randn(n_out, device=DEV))
     res = bf(torch.randn(M, n_out, device=DEV))
     out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    ws = torch.empty(16 * 128 * N, device=DEV, dtype=torch.float32) if splitk != 1 else None
+    ws = torch.empty(16 * max(M, 128) * N, device=DEV, dtype=torch.float32) if splitk != 1 else None
     K.gemm(out, x, wp, bias, res, ws, N, epi, splitk, ntw)
     want = ref.gemm(x, w_ref, bias, res, epi)
     assert_close(out, want, 3e-2 if not out_f32 else 2e-3, 2e-2 if not out_f32 else 2e-3,
@@ -140,7 +140,7 @@ def _gemm_w8_case(K, M, N, Kd, epi, splitk, out_f32=False, seed=0, ntw=0):
         n_out = N
     bias = bf(torch.randn(n_out, device=DEV))
     res = bf(torch.randn(M, n_out, device=DEV))
-    ws = torch.full((16 * 128 * N,), float("nan"), device=DEV, dtype=torch.float32) if (splitk != 1 or epi == 6) else None
+    ws = torch.full((16 * max(M, 128) * N,), float("nan"), device=DEV, dtype=torch.float32) if (splitk != 1 or epi == 6) else None
     if epi == 6:
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         K.gemm_w8(out, x, wp, sc, None, None, ws, N, 6, splitk, ntw)
@@ -164,14 +164,14 @@ def test_gemm_w8_epilogues(K, M, epi):
 
 @pytest.mark.parametrize("chunks", [1, 2, 3, 4, 5, 6, 7, 9])
 def test_gemm_w8_ring_prefetch_edges(K, chunks):
-    for M in (8, 48, 128):
+    for M in (8, 48, 128, 250):
         for ntw in (1, 2):
             _gemm_w8_case(K, M, 2048, 128 * chunks, 0, 1, out_f32=True, ntw=ntw)
 
 
 def test_gemm_w8_prefill_slices(K):
     """More than 128 rows over fp8 weights: 128-row slices through the streaming kernel."""
-    _gemm_w8_case(K, 300, 1024, 512, 3, 1)
+    _gemm_w8_case(K, 600, 1024, 512, 3, 1)
     _gemm_w8_case(K, 257, 1024, 512, 4, 1)
 
 
@@ -199,7 +199,7 @@ def test_gemm_layout_identity(K):
     assert torch.equal(out, w.float().t()[:64])
 
 
-@pytest.mark.parametrize("M", [65, 100, 128])
+@pytest.mark.parametrize("M", [65, 100, 128, 129, 200, 256])
 @pytest.mark.parametrize("ntw", [1, 2])
 def test_gemm_skinny_128_rows(K, M, ntw):
     _gemm_case(K, M, 1024, 1024, 3, 1, ntw=ntw)
@@ -212,7 +212,7 @@ def test_gemm_skinny_ring_prefetch_edges(K, chunks):
     """K ranges of 1..9 LDS stages exercise every phase of the 2-deep weight ring (prologue, steady
     pairs, each peeled tail), for every row-tile count and both n-tile widths, on a grid big enough
     (N=2048) that waves really run with loads in flight."""
-    for M in (8, 24, 48, 128):
+    for M in (8, 24, 48, 128, 256):
         for ntw in (1, 2):
             _gemm_case(K, M, 2048, 128 * chunks, 0, 1, out_f32=True, ntw=ntw)
     _gemm_case(K, 40, 256, 128 * chunks, 2, 1, ntw=1)
@@ -249,7 +249,7 @@ def test_gemm_partials_consumed_by_norm_and_rope(K):
         assert_close(o3, ref.rmsnorm(hn[rows.long()], g, 1e-5), 3e-2, 2e-2, "row-gathered norm over partials")
 
 
-@pytest.mark.parametrize("M", [129, 300])
+@pytest.mark.parametrize("M", [257, 300])
 @pytest.mark.parametrize("epi", [0, 3, 4, 5])
 def test_gemm_tile(K, M, epi):
     _gemm_case(K, M, 1024, 512, epi, 1)
