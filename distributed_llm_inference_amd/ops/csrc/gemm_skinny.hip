@@ -223,6 +223,55 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
         }
       }
       const char* xb = smem + par * kStageBytes;
+      auto xfrag = [&](int i, int kk) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>(xb + (i * 16 + l15) * 256 + (((kk * 4 + quad) ^ l15) << 4));
+      };
+      if constexpr (XDMA && !W8) {
+        // One wave per SIMD here (128 KiB of LDS per workgroup), so nothing else hides the LDS
+        // latency: the x fragments of k-step kk+1 are fetched while the MFMAs of kk run. (Not for
+        // fp8 weights: with the widened fragments on top, the register file no longer fits both
+        // fragment sets and hipcc starts copying ring registers that are still in flight.)
+        u32x4 xa[MT], xb2[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) xa[i] = xfrag(i, 0);
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) {
+          if constexpr (refill) wait_vm<kWaitW>();
+          u32x4 wf[KPS][NTW];
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            const u32x4 raw = w[par * SL + sl][j];
+            if constexpr (W8) {
+              wf[0][j] = fp8x8_to_bf16x8(raw[0], raw[1]);
+              wf[KPS - 1][j] = fp8x8_to_bf16x8(raw[2], raw[3]);
+            } else {
+              wf[0][j] = raw;
+            }
+          }
+          if constexpr (refill && W8) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
+          }
+#pragma unroll
+          for (int ks2 = 0; ks2 < KPS; ++ks2) {
+            const int kk = sl * KPS + ks2;
+            u32x4(&cur)[MT] = (kk & 1) ? xb2 : xa;
+            u32x4(&nxt)[MT] = (kk & 1) ? xa : xb2;
+            if (kk + 1 < 4) {
+#pragma unroll
+              for (int i = 0; i < MT; ++i) nxt[i] = xfrag(i, kk + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(wf[ks2][j], cur[i], acc[i][j]);
+          }
+          if constexpr (refill && !W8) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
+          }
+        }
+      } else {
 #pragma unroll
       for (int sl = 0; sl < SL; ++sl) {
         if constexpr (refill) wait_vm<kWaitW>();
@@ -246,8 +295,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
           const int kk = sl * KPS + ks2;
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            const int r = i * 16 + l15;
-            const u32x4 xf = *reinterpret_cast<const u32x4*>(xb + r * 256 + (((kk * 4 + quad) ^ l15) << 4));
+            const u32x4 xf = xfrag(i, kk);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(wf[ks2][j], xf, acc[i][j]);
           }
@@ -256,6 +304,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
 #pragma unroll
           for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
         }
+      }
       }
       if constexpr (XDMA) {                        // x(c+1) must be in LDS before anyone passes the barrier
         if constexpr (refill) wait_vm<kWaitX>();
