@@ -148,7 +148,9 @@ class GpuStage:
                              (2 * I if spec.is_llama else I, H, 4 if spec.is_llama else 5),
                              (packing.padded_n(V), H, 0)):
             for m_ in range(1, DECODE_ROWS + 1):    # any token count up to this takes the weight-streaming path
-                need = max(need, int(self.K.gemm_config(m_, n_, k_, e_, True)[1]) * m_ * n_)
+                sk = int(self.K.gemm_config(m_, n_, k_, e_, True)[1])
+                if e_ == 6 or sk > 1:               # direct epilogues of an unsplit GEMM need no partials
+                    need = max(need, sk * m_ * n_)
         self._ws_floats = need
         self.wk0 = self._new_work(self.max_tokens)
         # eager-path metadata (device) + pinned staging
