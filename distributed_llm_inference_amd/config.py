@@ -56,6 +56,7 @@ class EngineConfig:
     health_timeout_s: float = 5.0          # orchestration.py:313
     debug_top5: bool = False               # orchestration.py:172-178
     trace_path: Optional[str] = None       # write a Chrome trace of step timelines here
+    auto_restart: bool = False             # rebuild the pipeline (new processes, new communicators) after a fatal stage failure
     # ---- fault injection (tests) ------------------------------------------------------
     fault_inject: str = ""                 # e.g. "stage1:exit@3", "stage1:stall@2:5.0", "stage0:raise@1"
 

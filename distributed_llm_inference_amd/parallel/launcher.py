@@ -103,7 +103,7 @@ class LocalPipeline:
         exs = executors or [build_executor(cfg, self.spec, p) for p in self.plans]
         self.executors = exs
         self.tracer = make_tracer(cfg.trace_path)      # one process: all stages share the tracer
-        self.runtimes = [StageRuntime(ex, l, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams,
+        self.runtimes = [StageRuntime(ex, l, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
                                       trace_path=cfg.trace_path if l.stage == 0 else None)
                          for ex, l in zip(exs, links)]
         for p in self.plans:
@@ -144,7 +144,7 @@ def init_distributed(rank: int, world: int, backend: str, master_port: int, devi
     import datetime
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(master_port))
+    os.environ["MASTER_PORT"] = str(master_port)       # not setdefault: a rebuilt pipeline gets a new port
     kw = {}
     if backend == "nccl" and device is not None:
         torch.cuda.set_device(torch.device(device))
@@ -181,7 +181,7 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
 def _worker_entry(cfg_dict: dict, rank: int, world: int, job: str, master_port: int):
     cfg = EngineConfig.from_dict(cfg_dict)
     spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, master_port)
-    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path), decode_streams=cfg.decode_streams,
+    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path), decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
                       trace_path=cfg.trace_path)
     try:
         stage_main(rt)
@@ -221,7 +221,7 @@ class SpawnedPipeline:
             self.board.set_state(0, ST_ERROR, f"{type(e).__name__}: {e}")
             raise
         self.tracer = make_tracer(cfg.trace_path)
-        self.runtime = StageRuntime(ex, self.links, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams,
+        self.runtime = StageRuntime(ex, self.links, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
                                     trace_path=cfg.trace_path)
         self.board.set_state(0, ST_READY)
         self.tokenizer = make_tokenizer(cfg, self.spec)
@@ -270,7 +270,7 @@ def attach_distributed(cfg: EngineConfig):
         # rank 0 creates the board; others attach with retry inside StatusBoard
         pass
     spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, port, local_rank=local_rank)
-    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path), decode_streams=cfg.decode_streams,
+    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path), decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
                       trace_path=cfg.trace_path)
     return rank, world, rt, board, spec, cfg
 

@@ -65,7 +65,7 @@ class FaultInjector:
 
 class StageRuntime:
     def __init__(self, executor, links: PipelineLinks, board=None, fault: str = "", tracer=None,
-                 trace_path: Optional[str] = None, decode_streams: int = 3):
+                 trace_path: Optional[str] = None, decode_streams: int = 3, debug_top5: bool = False):
         self.ex = executor
         self.links = links
         self.board = board
@@ -83,6 +83,8 @@ class StageRuntime:
         self._local_fb: Dict[int, torch.Tensor] = {}   # single-stage pipeline: last tokens per micro-batch
         self.steps = 0
         self.barrier_times: List[float] = []
+        self.debug_top5 = debug_top5      # log the 5 most likely tokens of a request's first 3 draws
+        self.top5_log: List[dict] = []
         # Decode micro-batches own their workspaces, so consecutive micro-batches go to different
         # HIP streams: the ramp-up and tail of one micro-batch's kernels (and its recv/send) overlap
         # the other's instead of leaving the chip part-idle at every kernel boundary. Eager steps
@@ -94,7 +96,7 @@ class StageRuntime:
 
     # ---- helpers ---------------------------------------------------------------------------
     def _graph_decode(self, desc: StepBatch) -> bool:
-        return desc.is_decode and hasattr(self.ex, "decode_step")
+        return desc.is_decode and hasattr(self.ex, "decode_step") and not self.debug_top5
 
     def result_count(self, desc: StepBatch) -> int:
         """Number of token ids the last stage produces for `desc`: a static-buffer decode step
@@ -208,6 +210,8 @@ class StageRuntime:
         else:
             out = self.ex.forward(desc, x)
             if L.is_last:
+                if self.debug_top5:
+                    self._log_top5(desc, out)
                 out = self.ex.sample(desc, out)
             elif L.num_stages > 1:
                 out = out.clone()     # eager outputs alias a workspace the next step overwrites
@@ -233,6 +237,25 @@ class StageRuntime:
             self.tracer.span(f"stage{self.stage}.host", "enqueue step", t_start, time.perf_counter_ns(),
                              {"mb": mb, "tokens": T, "decode": desc.is_decode})
         return result
+
+    def _log_top5(self, desc: StepBatch, logits: torch.Tensor):
+        """The reference prints the top-5 candidates of the first three generation steps
+        (orchestration.py:172-178). Here: logged per sampled row whose draw counter is < 3, from
+        the logits of an eager step (the debug flag turns graph capture off for that reason)."""
+        from ..runtime.sampler import top_candidates
+        from ..utils.tracing import get_logger
+        rows = [i for i in range(desc.num_seqs) if desc.sample[i] and desc.q_lens[i] > 0]
+        lg = logits.detach().float().cpu()
+        for k, i in enumerate(rows):
+            if desc.sample_steps[i] >= 3 or k >= lg.shape[0]:
+                continue
+            probs, ids = top_candidates(lg[k], desc.temperature[i], desc.top_k[i], desc.top_p[i], 5)
+            rec = {"slot": desc.slots[i], "draw": desc.sample_steps[i],
+                   "top5": [(int(t), round(float(pr), 4)) for pr, t in zip(probs, ids)]}
+            if len(self.top5_log) < 4096:
+                self.top5_log.append(rec)
+            get_logger().info("top-5 slot %d draw %d: %s", rec["slot"], rec["draw"],
+                              ", ".join(f"{t} ({pr:.1%})" for t, pr in rec["top5"]))
 
     def barrier(self):
         """Finish everything this stage has enqueued, then meet the other stages. Records the

@@ -553,6 +553,10 @@ class Engine:
         r.output.append(tok)
         r.token_times.append(now)
         self.stats["tokens_out"] += 1
+        if self.cfg.debug_top5 and len(r.output) % 5 == 0:      # progress line (orchestration.py:194-196)
+            from ..utils.tracing import get_logger
+            get_logger().info("request %d: %d tokens so far: %r", r.rid, len(r.output),
+                              self.tok.decode(r.output, skip_special_tokens=True))
         if len(r.output) >= r.params.max_new_tokens or len(r.prompt_ids) + len(r.output) >= self.cfg.max_seq_len:
             self._finish(r, now)
 

@@ -39,6 +39,7 @@ def _add_engine_args(ap):
     ap.add_argument("--seed", type=int)
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--debug-top5", action="store_true")
+    ap.add_argument("--auto-restart", action="store_true", help="rebuild the pipeline after a fatal stage failure")
     ap.add_argument("--fault-inject")
     ap.add_argument("--trace", dest="trace_path", help="write a Chrome-trace JSON of the step timelines here")
 
@@ -60,6 +61,8 @@ def config_from_args(a) -> EngineConfig:
         base["use_graphs"] = False
     if getattr(a, "debug_top5", False):
         base["debug_top5"] = True
+    if getattr(a, "auto_restart", False):
+        base["auto_restart"] = True
     if getattr(a, "pp_size", None) is not None and getattr(a, "num_micro_batches", None) is None:
         base["num_micro_batches"] = 0
     return EngineConfig.from_dict(base)

@@ -17,6 +17,8 @@ parity). Handlers only enqueue and wait; all serving state lives in the engine's
 """
 from __future__ import annotations
 
+import threading
+
 import itertools
 import time
 from typing import Dict, List, Optional
@@ -34,13 +36,39 @@ _HEADERS = {"ngrok-skip-browser-warning": "true", "Content-Type": "application/j
 class EngineBackend:
     """/generate and /workers on top of a pipeline (`LocalPipeline` / `SpawnedPipeline`)."""
 
-    def __init__(self, pipeline):
+    def __init__(self, pipeline, factory=None):
         self.pipe = pipeline
         self.cfg: EngineConfig = pipeline.cfg
         self.engine = pipeline.engine
         self.model_name = pipeline.spec.name
+        self.restarts = 0
+        self._factory = factory
+        self._restart_lock = threading.Lock()
+
+    def _recover(self):
+        """Elastic recovery: the reference needs a human to restart a dead worker and re-paste its
+        URL (orchestration.py:22-24). With `auto_restart`, a pipeline whose engine went fatal (a
+        stage died, reported an error or stalled) is torn down — processes, process groups,
+        shared-memory rings — and rebuilt before the next request; requests that were in flight
+        at the failure have already been answered with the error envelope."""
+        if not (self.cfg.auto_restart and self.engine.fatal):
+            return
+        with self._restart_lock:
+            if not self.engine.fatal:
+                return
+            import dataclasses
+            from ..parallel.launcher import make_pipeline
+            try:
+                self.pipe.close()
+            except Exception:
+                pass
+            cfg = dataclasses.replace(self.cfg, fault_inject="")      # injected faults are one-shot
+            self.pipe = (self._factory or make_pipeline)(cfg)
+            self.cfg, self.engine = self.pipe.cfg, self.pipe.engine
+            self.restarts += 1
 
     def generate(self, prompt, max_new_tokens, temperature):
+        self._recover()
         return self.engine.generate_text(prompt, max_new_tokens=max_new_tokens, temperature=temperature,
                                          top_k=self.cfg.top_k, top_p=self.cfg.top_p)
 

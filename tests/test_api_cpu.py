@@ -217,6 +217,24 @@ def test_stage_failure_fails_requests_and_shows_in_workers():
         b.close()
 
 
+def test_auto_restart_rebuilds_the_pipeline_after_a_stage_died():
+    """Elastic recovery: with auto_restart the next request after a fatal stage failure gets a
+    fresh pipeline (new stage processes, new process groups) and succeeds."""
+    pipe = make_pipeline(cfg(pp_size=2, partition="even", transport="gloo", fault_inject="stage1:exit@3",
+                             hop_timeout_s=5, auto_restart=True))
+    b = EngineBackend(pipe)
+    try:
+        first = b.generate("Hello", 20, 0.0)
+        assert first["status"] == "failed"
+        assert b.workers()["worker_2"] == "offline"
+        second = b.generate("Hello", 6, 0.0)
+        assert second["status"] == "success" and second["tokens_generated"] == 6, second
+        assert b.restarts == 1
+        assert b.workers() == {"worker_1": "online", "worker_2": "online"}
+    finally:
+        b.close()
+
+
 def test_injected_exception_on_a_thread_stage_is_reported():
     pipe = LocalPipeline(cfg(pp_size=2, partition="even", fault_inject="stage1:raise@2", hop_timeout_s=2))
     try:
