@@ -150,7 +150,7 @@ def init_distributed(rank: int, world: int, backend: str, master_port: int, devi
         torch.cuda.set_device(torch.device(device))
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=180), **kw)
+                                timeout=datetime.timedelta(seconds=600), **kw)
     return dist
 
 

@@ -19,7 +19,7 @@ class RingClosed(Exception):
 class ShmRing:
     """One direction of one pipeline edge. Exactly one producer process and one consumer."""
 
-    def __init__(self, name: str, create: bool, slots: int = 256, slot_bytes: int = 65536, timeout_s: float = 60.0):
+    def __init__(self, name: str, create: bool, slots: int = 256, slot_bytes: int = 65536, timeout_s: float = 300.0):
         self._L = native.lib()
         self.name = name if name.startswith("/") else "/" + name
         self._h = self._L.dlia_ring_open(self.name.encode(), 1 if create else 0, slots, slot_bytes, int(timeout_s * 1000))
@@ -69,7 +69,7 @@ class ShmRing:
 
 
 class StatusBoard:
-    def __init__(self, name: str, create: bool, num_stages: int = 0, timeout_s: float = 60.0):
+    def __init__(self, name: str, create: bool, num_stages: int = 0, timeout_s: float = 300.0):
         self._L = native.lib()
         self.name = name if name.startswith("/") else "/" + name
         self._h = self._L.dlia_board_open(self.name.encode(), 1 if create else 0, num_stages, int(timeout_s * 1000))
