@@ -67,6 +67,12 @@ __device__ __forceinline__ void gload_lds16(const void* gptr, unsigned lds_addr)
                "s_nop 0\n\ts_mov_b32 m0, %0"
                : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
 }
+// `c ? a : b` on pointers without a branch: hipcc otherwise branches around the load that follows,
+// and a load that sits on one arm of a diamond can no longer be counted by hand (nor by the lint).
+__device__ __forceinline__ const void* sel_ptr(bool c, const void* a, const void* b) {
+  const long d = reinterpret_cast<const char*>(a) - reinterpret_cast<const char*>(b);
+  return reinterpret_cast<const char*>(b) + (d & -static_cast<long>(c));
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
@@ -84,21 +90,30 @@ __device__ __forceinline__ u32x4 fp8x8_to_bf16x8(unsigned d0, unsigned d1) {
                fp8x2_to_bf16x2(d1, true)};
 }
 
-template <int MT, int NTW, bool W8>
-__global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (MT*16 rows x 256 B)
-  constexpr int kStageBytes = MT * 16 * 256;
+// BK = K elements per chunk (one LDS stage of x). 128 everywhere except the 256-row variant, whose
+// two 64 KiB stages would allow only one workgroup — one wave per SIMD — per CU; with BK = 64 two
+// workgroups share a CU and each covers the other's barrier, LDS and load stalls.
+// OCC = waves per SIMD the register budget is sized for.
+template <int MT, int NTW, bool W8, int BK, int OCC>
+__global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of MT*16 rows x BK bf16
+  constexpr int KSTEPS = BK / 32;                // MFMA k-steps per chunk
+  constexpr int ROWB = BK * 2;                   // bytes of one x row in an LDS stage
+  constexpr int kStageBytes = MT * 16 * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
   const int nblk = blockIdx.x, ks = blockIdx.y;
-  constexpr int SL = W8 ? 2 : 4;                 // 16-B ring slots per chunk and n-tile
-  constexpr int KPS = 4 / SL;                    // MFMA k-steps held by one slot
+  constexpr int SL = W8 ? KSTEPS / 2 : KSTEPS;   // 16-B ring slots per chunk and n-tile
+  constexpr int KPS = KSTEPS / SL;               // MFMA k-steps held by one slot
   const int KT = p.K / (32 * KPS);               // slots in K per n-tile
-  const int chunks_total = p.K / kSkinnyBK;
+  const int chunks_total = p.K / BK;
   const int cper = (chunks_total + p.splitk - 1) / p.splitk;
   const int c0 = ks * cper;
   const int c1 = min(chunks_total, c0 + cper);
-  const int n = c1 - c0;                         // LDS stages (chunks of 128 K-elements) of this split
+  const int n = c1 - c0;                         // LDS stages (chunks of BK K-elements) of this split
+  // 16-B slot swizzle of an x row in LDS: 256-B rows all start at bank 0, so 16 consecutive rows
+  // take 16 different slots; 128-B rows alternate between two bank halves, so row pairs do.
+  auto swz = [](int row) { return BK == 128 ? (row & 15) : ((row >> 1) & 7); };
   const int tile0 = (nblk * 4 + wave) * NTW;     // first n-tile of this wave
   const bool wave_active = tile0 < p.ntiles;     // (ntiles is a multiple of 8 by packing)
 
@@ -107,25 +122,36 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
   // 4 KiB step from piece 0 (an immediate offset) and only one source pointer is kept; rows past
   // M re-read the last row (never stored to the output).
   const int srow = tid >> 4, sslot = tid & 15;
-  const bf16* xbase = p.x + sslot * 8 + (long)c0 * kSkinnyBK;
+  const bf16* xbase = p.x + sslot * 8 + (long)c0 * BK;
   const int xdst0 = srow * 256 + ((sslot ^ (srow & 15)) << 4);
   auto xsrc = [&](int i, int c) -> const bf16* {
     const int r = srow + 16 * i;
-    return xbase + (long)(r < p.M ? r : p.M - 1) * p.ldx + (long)c * kSkinnyBK;
+    return xbase + (long)(r < p.M ? r : p.M - 1) * p.ldx + (long)c * BK;
   };
-  // 256-row variant (MT == 16): the register file cannot also hold a chunk of x, so x goes
-  // global -> LDS by DMA. Wave instruction Q = wave*MT + q fills rows 4Q..4Q+3 (1 KiB); the LDS image
-  // must be lane-linear, so the XOR swizzle is applied to the SOURCE column instead.
+  // 256-row variants (MT == 16): the register file cannot also hold a chunk of x, so x goes
+  // global -> LDS by DMA. One wave instruction fills 1 KiB = RPI rows; wave instruction
+  // Q = wave*XL + q fills rows RPI*Q .. RPI*Q + RPI-1. The LDS image must be lane-linear, so the XOR
+  // swizzle is applied to the SOURCE column instead.
   constexpr bool XDMA = MT >= 16;
+  // At two waves per SIMD the peeled tail bodies (each a separately register-allocated copy of 64+
+  // MFMAs) make hipcc shuffle accumulators through scratch at every join. That variant keeps ONE
+  // body per chunk parity instead: loads for chunks past the end of the split are still issued,
+  // against a dummy address, so the hand-counted waits stay valid to the last chunk.
+  constexpr bool UNIFORM = XDMA && OCC >= 2;
+  const void* const dummy = p.x;                 // 16 valid, L2-hot bytes; every lane reads the same line
+  static_assert(XDMA || BK == 128, "register staging is laid out for 256-B rows");
+  constexpr int RPI = 1024 / ROWB;                       // rows per DMA instruction (4 or 8)
+  constexpr int LPR = ROWB / 16;                         // lanes (16-B slots) per row (16 or 8)
+  constexpr int XL = MT * 16 / RPI / 4;                  // DMA instructions per wave and chunk
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   auto xdma = [&](int stage, int c) {
 #pragma unroll
-    for (int q = 0; q < MT; ++q) {
-      const int row = 4 * (wv * MT + q) + quad;
-      const bf16* src = p.x + (long)(row < p.M ? row : p.M - 1) * p.ldx + ((l15 ^ (row & 15)) << 3) +
-                        (long)(c0 + c) * kSkinnyBK;
-      gload_lds16(src, lds0 + stage * kStageBytes + (wv * MT + q) * 1024);
+    for (int q = 0; q < XL; ++q) {
+      const int row = RPI * (wv * XL + q) + lane / LPR;
+      const bf16* src = p.x + (long)(row < p.M ? row : p.M - 1) * p.ldx + (((lane % LPR) ^ swz(row)) << 3) +
+                        (long)(c0 + c) * BK;
+      gload_lds16(src, lds0 + stage * kStageBytes + (wv * XL + q) * 1024);
     }
   };
   const u32x4* wbase[NTW];
@@ -148,7 +174,8 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
     // refill of slot s [NTW loads]. Hence, in steady state (SL slots per chunk):
     //   x(c+1) has SL*NTW younger loads when chunk c starts              -> vmcnt(SL*NTW)
     //   slot s of chunk c has (2*SL-1)*NTW + 2*MT younger loads at its use -> vmcnt of that
-    constexpr int kWaitX = SL * NTW, kWaitW = (2 * SL - 1) * NTW + 2 * MT;
+    constexpr int XLOADS = XDMA ? XL : MT;           // x loads per wave (thread) and chunk
+    constexpr int kWaitX = SL * NTW, kWaitW = (2 * SL - 1) * NTW + 2 * XLOADS;
     static_assert(kWaitW <= 63, "vmcnt is a 6-bit counter");
     u32x4 w[2 * SL][NTW], xr[MT];
     if constexpr (!XDMA) {
@@ -181,11 +208,12 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
 #pragma unroll
         for (int j = 0; j < NTW; ++j) gload16_nt(w[sl][j], wbase[j] + (long)sl * 64);
       xdma(0, 0);
-      if (n > 1) {
+      if (UNIFORM || n > 1) {
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) gload16_nt(w[SL + sl][j], wbase[j] + (long)(SL + sl) * 64);
+          for (int j = 0; j < NTW; ++j)
+            gload16_nt(w[SL + sl][j], sel_ptr(n > 1, wbase[j] + (long)(SL + sl) * 64, dummy));
         wait_vm<SL * NTW>();                       // x(0) in LDS; w(1) may still fly
       } else {
         wait_vm<0>();
@@ -200,10 +228,10 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
       constexpr bool refill = decltype(REFILL)::value != 0;
       if constexpr (XDMA) {
         if constexpr (refill) {
-          xdma(par ^ 1, c + 1);
+          xdma(par ^ 1, UNIFORM ? min(c + 1, n - 1) : c + 1);
         } else if (c + 1 < n) {
           xdma(par ^ 1, c + 1);
-          wait_vm<MT>();                           // everything but the DMA just issued
+          wait_vm<XL>();                           // everything but the DMA just issued
         } else {
           wait_vm<0>();
         }
@@ -224,9 +252,9 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
       }
       const char* xb = smem + par * kStageBytes;
       auto xfrag = [&](int i, int kk) -> u32x4 {
-        return *reinterpret_cast<const u32x4*>(xb + (i * 16 + l15) * 256 + (((kk * 4 + quad) ^ l15) << 4));
+        return *reinterpret_cast<const u32x4*>(xb + (i * 16 + l15) * ROWB + (((kk * 4 + quad) ^ swz(l15)) << 4));
       };
-      if constexpr (XDMA && !W8) {
+      if constexpr (XDMA && !W8 && OCC == 1) {
         // One wave per SIMD here (128 KiB of LDS per workgroup), so nothing else hides the LDS
         // latency: the x fragments of k-step kk+1 are fetched while the MFMAs of kk run. (Not for
         // fp8 weights: with the widened fragments on top, the register file no longer fits both
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
             const int kk = sl * KPS + ks2;
             u32x4(&cur)[MT] = (kk & 1) ? xb2 : xa;
             u32x4(&nxt)[MT] = (kk & 1) ? xa : xb2;
-            if (kk + 1 < 4) {
+            if (kk + 1 < KSTEPS) {
 #pragma unroll
               for (int i = 0; i < MT; ++i) nxt[i] = xfrag(i, kk + 1);
             }
@@ -288,21 +316,41 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
         }
         if constexpr (refill && W8) {             // the raw slot is free once widened
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
+          for (int j = 0; j < NTW; ++j)
+            gload16_nt(w[par * SL + sl][j], sel_ptr(!UNIFORM || c + 2 < n, wbase[j] + (long)((c + 2) * SL + sl) * 64, dummy));
         }
 #pragma unroll
         for (int ks2 = 0; ks2 < KPS; ++ks2) {
           const int kk = sl * KPS + ks2;
+          if constexpr (XDMA) {
+            // 256 rows at two waves per SIMD: 128 accumulator registers leave ~100 for everything
+            // else, so fragments are fetched four m-tiles at a time and a scheduling barrier per
+            // group stops hipcc from hoisting a whole k-step of them (which spills); the LDS
+            // latency of a group is covered by the other workgroup on the CU.
 #pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            const u32x4 xf = xfrag(i, kk);
+            for (int ig = 0; ig < MT / 4; ++ig) {
+              u32x4 xf[4];
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(wf[ks2][j], xf, acc[i][j]);
+              for (int i4 = 0; i4 < 4; ++i4) xf[i4] = xfrag(ig * 4 + i4, kk);
+#pragma unroll
+              for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[ig * 4 + i4][j] = mfma16(wf[ks2][j], xf[i4], acc[ig * 4 + i4][j]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const u32x4 xf = xfrag(i, kk);
+#pragma unroll
+              for (int j = 0; j < NTW; ++j) acc[i][j] = mfma16(wf[ks2][j], xf, acc[i][j]);
+            }
           }
         }
         if constexpr (refill && !W8) {
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) gload16_nt(w[par * SL + sl][j], wbase[j] + (long)((c + 2) * SL + sl) * 64);
+          for (int j = 0; j < NTW; ++j)
+            gload16_nt(w[par * SL + sl][j], sel_ptr(!UNIFORM || c + 2 < n, wbase[j] + (long)((c + 2) * SL + sl) * 64, dummy));
         }
       }
       }
@@ -313,11 +361,20 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_skinny_kernel(GemmParams 
       __syncthreads();
     };
     int c = 0;
+    if constexpr (UNIFORM) {
+      for (; c < n; c += 2) {
+        body(IntC<0>{}, IntC<1>{}, c);
+        if (c + 1 < n) body(IntC<1>{}, IntC<1>{}, c + 1);
+      }
+      wait_vm<0>();                               // the dummy loads must land before their registers are reused
+      c = n;
+    }
     for (; c + 3 < n; c += 2) {                  // both chunks of the pair have a chunk two ahead
       body(IntC<0>{}, IntC<1>{}, c);
       body(IntC<1>{}, IntC<1>{}, c + 1);
     }
-    if (n - c == 3) {
+    if (UNIFORM) {
+    } else if (n - c == 3) {
       body(IntC<0>{}, IntC<1>{}, c);
       body(IntC<1>{}, IntC<0>{}, c + 1);
       body(IntC<0>{}, IntC<0>{}, c + 2);
@@ -407,32 +464,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   epilogue4(p, m, n, g, u);
 }
 
-constexpr bool smem_needs_opt_in(int mt) { return 2 * mt * 16 * 256 > 64 * 1024; }
-
-template <int MT, int NTW>
+template <int MT, int NTW, int BK, int OCC>
 static void launch_skinny(const GemmParams& p, hipStream_t stream) {
   const int nblocks = (p.ntiles + 4 * NTW - 1) / (4 * NTW);
   dim3 grid(nblocks, p.splitk), block(kSkinnyThreads);
-  const size_t smem = 2 * MT * 16 * 256;
-  if constexpr (smem_needs_opt_in(MT)) {          // more than 64 KiB of dynamic LDS is opt-in, once per kernel
+  constexpr int smem = 2 * MT * 16 * BK * 2;
+  if constexpr (smem > 64 * 1024) {               // more than 64 KiB of dynamic LDS is opt-in, once per kernel
     static const bool once = [] {
-      const int bytes = 2 * MT * 16 * 256;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NTW, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NTW, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NTW, true, BK, OCC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NTW, false, BK, OCC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       return true;
     }();
     (void)once;
   }
-  if (p.wscale) hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, true>), grid, block, smem, stream, p);
-  else          hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, false>), grid, block, smem, stream, p);
+  if (p.wscale) hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, true, BK, OCC>), grid, block, smem, stream, p);
+  else          hipLaunchKernelGGL((gemm_skinny_kernel<MT, NTW, false, BK, OCC>), grid, block, smem, stream, p);
 }
 
 template <int MT>
 static void launch_skinny_ntw(const GemmParams& p, int ntw, hipStream_t stream) {
-  if (ntw == 1) launch_skinny<MT, 1>(p, stream);
-  else          launch_skinny<MT, 2>(p, stream);
+  if constexpr (MT == 16) {
+    static const bool one_per_cu = [] { const char* e = getenv("DLIA_GEMM_256_ONE_PER_CU"); return e && atoi(e) != 0; }();
+    if (one_per_cu) {                             // 128-wide chunks, one workgroup per CU (kept for A/B runs)
+      if (ntw == 1) launch_skinny<MT, 1, 128, 1>(p, stream);
+      else          launch_skinny<MT, 2, 128, 1>(p, stream);
+    } else {
+      if (ntw == 1) launch_skinny<MT, 1, 64, 2>(p, stream);
+      else          launch_skinny<MT, 2, 64, 2>(p, stream);
+    }
+  } else {
+    if (ntw == 1) launch_skinny<MT, 1, 128, 1>(p, stream);
+    else          launch_skinny<MT, 2, 128, 1>(p, stream);
+  }
 }
 
 }  // namespace dlia
