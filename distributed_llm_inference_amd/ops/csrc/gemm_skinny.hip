@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmPa
   // MFMAs) make hipcc shuffle accumulators through scratch at every join. That variant keeps ONE
   // body per chunk parity instead: loads for chunks past the end of the split are still issued,
   // against a dummy address, so the hand-counted waits stay valid to the last chunk.
-  constexpr bool UNIFORM = XDMA && OCC >= 2;
+  constexpr bool UNIFORM = OCC >= 2;
   const void* const dummy = p.x;                 // 16 valid, L2-hot bytes; every lane reads the same line
   static_assert(XDMA || BK == 128, "register staging is laid out for 256-B rows");
   constexpr int RPI = 1024 / ROWB;                       // rows per DMA instruction (4 or 8)
@@ -190,13 +190,14 @@ __global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmPa
       wait_vm<SL * NTW>();
 #pragma unroll
       for (int i = 0; i < MT; ++i) st16(smem + xdst0 + i * 4096, xr[i]);
-      if (n > 1) {
+      if (UNIFORM || n > 1) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc(i, 1));
+        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc(i, UNIFORM ? min(1, n - 1) : 1));
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) gload16_nt(w[SL + sl][j], wbase[j] + (long)(SL + sl) * 64);
+          for (int j = 0; j < NTW; ++j)
+            gload16_nt(w[SL + sl][j], sel_ptr(!UNIFORM || n > 1, wbase[j] + (long)(SL + sl) * 64, dummy));
       }
     } else {
       // DMA variant: chunk c issues x(c+1) (into the LDS stage chunk c-1 just released) and then
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmPa
 #pragma unroll
         for (int i = 0; i < MT; ++i) st16(xn + xdst0 + i * 4096, xr[i]);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc(i, c + 2));
+        for (int i = 0; i < MT; ++i) gload16(xr[i], xsrc(i, UNIFORM ? min(c + 2, n - 1) : c + 2));
       } else {
         wait_vm<0>();
         if (c + 1 < n) {
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmPa
 #pragma unroll
         for (int ks2 = 0; ks2 < KPS; ++ks2) {
           const int kk = sl * KPS + ks2;
-          if constexpr (XDMA) {
+          if constexpr (XDMA || (OCC >= 2 && MT >= 4)) {
             // 256 rows at two waves per SIMD: 128 accumulator registers leave ~100 for everything
             // else, so fragments are fetched four m-tiles at a time and a scheduling barrier per
             // group stops hipcc from hoisting a whole k-step of them (which spills); the LDS
