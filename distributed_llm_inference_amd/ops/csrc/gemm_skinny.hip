@@ -524,10 +524,7 @@ extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_
       const char* e = getenv("DLIA_GEMM_TARGET_WGS");
       return e ? atoi(e) : 0;
     }();
-    // Large micro-batches run two at a time on two streams (the other stream fills the idle CUs),
-    // and their partials are big: split less. Measured with bench.py at 128 rows: 96 beats 192 by 2.5 %.
-    // Beyond 128 rows the kernel is MFMA/LDS-bound with one wave per SIMD: more, shorter workgroups win again.
-    const int target = forced > 0 ? forced : (M > 64 && M <= 128 ? 96 : 192);
+    const int target = forced > 0 ? forced : 192;
     while (nblocks * s < target && s < 16 && chunks / (s * 2) >= 2) s *= 2;
     const double cap = M > 128 ? 36.0e6 : 20.0e6;                  // cap the fp32 partial traffic
     while (s > 1 && (double)s * M * N * 4.0 > cap) s /= 2;
