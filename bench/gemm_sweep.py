@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--m", type=int, nargs="+", default=[64])
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--a8w8", action="store_true", help="sweep the fp8 x fp8 kernel instead of the bf16 one")
     a = ap.parse_args()
     K = ops.load()
     s = ModelSpec.from_pretrained(a.model)
@@ -29,7 +30,13 @@ def main():
     for M in a.m:
         for name, N, Kd, epi in shapes:
             x = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
-            wp = packing.pack_weight((torch.randn(N, Kd, device="cuda") * 0.02).to(torch.bfloat16))
+            wraw = torch.randn(N, Kd, device="cuda") * 0.02
+            wp = packing.pack_weight(wraw.to(torch.bfloat16))
+            if a.a8w8:
+                wq, wsc = packing.pack_weight_a8w8(wraw)
+                xq = torch.zeros(M, Kd, device="cuda", dtype=torch.uint8)
+                xs = torch.zeros(M, device="cuda")
+                K.quant_rows(xq, xs, x)
             n_out = N // 2 if epi == 4 else N
             out = torch.empty(M, n_out, device="cuda", dtype=torch.float32 if name == "lm_head" else torch.bfloat16)
             ws = torch.empty(16 * M * N, device="cuda", dtype=torch.float32)
@@ -42,17 +49,20 @@ def main():
                     flush.fill_(it & 1)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    K.gemm(out, x, wp, None, None, ws, N, epi, sk, n)
+                    if a.a8w8:
+                        K.gemm_a8w8(out, xq, xs, wq, wsc, None, None, ws, N, epi, sk, n)
+                    else:
+                        K.gemm(out, x, wp, None, None, ws, N, epi, sk, n)
                     e1.record()
                     ev.append((e0, e1))
                 torch.cuda.synchronize()
                 ts = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in ev[2:])
                 res[(n, sk)] = ts[len(ts) // 2]
             best = min(res, key=res.get)
-            gb = N * Kd * 2 / 1e3
+            gb = N * Kd * (1 if a.a8w8 else 2) / 1e3
             line = " ".join(f"{n}/{sk}:{t:5.1f}" for (n, sk), t in sorted(res.items()))
             print(f"M={M:3d} {name:8s} N={N:6d} K={Kd:5d} | auto {auto} {res.get(auto, float('nan')):5.1f}us "
-                  f"({gb / res.get(auto, 1e9):.2f} TB/s) | best {best} {res[best]:5.1f}us ({gb / res[best]:.2f} TB/s) | {line}",
+                  f"({gb / res.get(auto, 1e9):.0f} GB/s) | best {best} {res[best]:5.1f}us ({gb / res[best]:.0f} GB/s) | {line}",
                   flush=True)
 
 

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--seqs", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", type=int, default=0)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"])
     a = ap.parse_args()
     spec = ModelSpec.from_pretrained(a.model)
     if a.layers:

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--layers", type=int, default=0, help="truncate the model (profiling)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"])
     a = ap.parse_args()
     spec = ModelSpec.from_pretrained(a.model)
     if a.layers:

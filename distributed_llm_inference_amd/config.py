@@ -19,7 +19,7 @@ class EngineConfig:
     # ---- model -------------------------------------------------------------------------
     model: str = "tinyllama-1.1b"          # built-in name or HF checkpoint directory
     weights: str = "auto"                  # "auto": checkpoint if `model` is a dir with weights, else random
-    dtype: str = "bf16"                    # GPU compute dtype: bf16 (fp8 weights: "fp8")
+    dtype: str = "bf16"                    # bf16 | fp8 (e4m3 weights x e4m3 activations on the fp8 MFMA) | fp8w (e4m3 weights only)
     seed: int = 0                          # random-init seed
     tokenizer: Optional[str] = None        # tokenizer directory (default: the model directory; else byte fallback)
     # ---- pipeline ----------------------------------------------------------------------
@@ -68,7 +68,7 @@ class EngineConfig:
         if self.layer_ranges is not None:
             self.layer_ranges = [tuple(r) for r in self.layer_ranges]
             self.partition = "explicit"
-        if self.dtype not in ("bf16", "fp32", "fp8"):
+        if self.dtype not in ("bf16", "fp32", "fp8", "fp8w"):
             raise ValueError(f"unsupported dtype {self.dtype!r}")
         if self.max_batch < 1 or self.max_seq_len < 8:
             raise ValueError("max_batch / max_seq_len out of range")

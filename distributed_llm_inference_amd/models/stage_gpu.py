@@ -47,6 +47,8 @@ class _Work:
     act: torch.Tensor            # bf16 [T, I]
     ws: torch.Tensor             # fp32 split-K partials [S, M, N], reused by every GEMM of the step
     attn_ws: torch.Tensor        # fp32 split-KV partials
+    xq: Optional[torch.Tensor]       # uint8 [T, max K] e4m3 activations (fp8 mode), one GEMM input at a time
+    xs: Optional[torch.Tensor]       # fp32 [T]         their per-row scales
     head_x: Optional[torch.Tensor]   # bf16 [B, H]      (last stage)
     logits: Optional[torch.Tensor]   # fp32 [B, vocab_pad]
 
@@ -82,10 +84,14 @@ class GpuStage:
             raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
         if spec.head_dim not in (64, 128):
             raise ValueError("the HIP attention kernels support head_dim 64 and 128")
-        if weight_dtype not in ("bf16", "fp8"):
-            raise ValueError("weight_dtype must be bf16 or fp8")
+        if weight_dtype not in ("bf16", "fp8", "fp8w"):
+            raise ValueError("weight_dtype must be bf16, fp8 or fp8w")
         self.K = ops.load()
-        self.w8 = weight_dtype == "fp8"       # decoder-layer GEMM weights as e4m3 + per-channel scale
+        # decoder-layer GEMMs: "fp8" = e4m3 weights (per-channel scale) x e4m3 activations (per-row
+        # dynamic scale) on the block-scaled fp8 MFMA; "fp8w" = e4m3 weights widened to bf16 in
+        # registers, bf16 activations
+        self.wmode = weight_dtype
+        self.w8 = weight_dtype != "bf16"
         self.spec, self.plan = spec, plan
         self.device = torch.device(device)
         self.max_slots, self.max_seq_len = max_slots, max_seq_len
@@ -174,23 +180,32 @@ class GpuStage:
             act=z(rows, s.intermediate_size), ws=z(self._ws_floats, dt=torch.float32),
             attn_ws=z(int(self.K.attention_ws_floats(B, 1, s.num_heads, s.num_kv_heads, s.head_dim, self.max_splits)),
                       dt=torch.float32),
+            xq=z(rows, max(s.hidden_size, s.q_size, s.intermediate_size), dt=torch.uint8) if self.wmode == "fp8" else None,
+            xs=z(rows, dt=torch.float32) if self.wmode == "fp8" else None,
             head_x=z(B, s.hidden_size) if self.plan.has_head else None,
             logits=z(B, self.vocab_pad, dt=torch.float32) if self.plan.has_head else None)
 
     def _pack(self, p: Dict[str, torch.Tensor], name: str, w: torch.Tensor):
         """Packs one GEMM weight into MFMA-fragment order; fp8 mode also stores `<name>_s` scales.
         (The lm_head stays bf16: logits feed a sampler and are the most precision-sensitive GEMM.)"""
-        if self.w8:
+        if self.wmode == "fp8":
+            p[name], p[name + "_s"] = packing.pack_weight_a8w8(w)
+        elif self.wmode == "fp8w":
             p[name], p[name + "_s"] = packing.pack_weight_fp8(w)
         else:
             p[name] = packing.pack_weight(w)
 
-    def _gemm(self, out, x, p, name, bias, residual, ws, N, epi, splitk, ntw):
+    def _gemm(self, wk, out, x, p, name, bias, residual, ws, N, epi, splitk, ntw):
         sc = p.get(name + "_s")
         if sc is None:
             self.K.gemm(out, x, p[name], bias, residual, ws, N, epi, splitk, ntw)
-        else:
+        elif self.wmode == "fp8w":
             self.K.gemm_w8(out, x, p[name], sc, bias, residual, ws, N, epi, splitk, ntw)
+        else:
+            T, Kd = x.shape
+            xq = wk.xq[:T, :Kd]
+            self.K.quant_rows(xq, wk.xs, x)
+            self.K.gemm_a8w8(out, xq, wk.xs, p[name], sc, bias, residual, ws, N, epi, splitk, min(ntw, 2))
 
     def _workspace_bytes(self) -> int:
         s = self.spec
@@ -237,19 +252,19 @@ class GpuStage:
             for li, p in enumerate(self.layers):
                 kv = self.kv[li]
                 K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
-                self._gemm(qkv, xn, p, "w_qkv", p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
+                self._gemm(wk, qkv, xn, p, "w_qkv", p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
                 K.rope_kvwrite(qkv, None, 1, None, kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
                                Hq, Hkv, D, llama)
                 K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
                                   self.scale, splits)
-                self._gemm(h, attn, p, "w_o", p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
+                self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
                 K.norm(xn, h, None, None, 1, None, p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
                 if llama:
-                    self._gemm(act, xn, p, "w_gu", None, None, None, 2 * I, 4, 1, 0)
-                    self._gemm(h, act, p, "w_down", None, h, None, H, 2, 1, 0)
+                    self._gemm(wk, act, xn, p, "w_gu", None, None, None, 2 * I, 4, 1, 0)
+                    self._gemm(wk, h, act, p, "w_down", None, h, None, H, 2, 1, 0)
                 else:
-                    self._gemm(act, xn, p, "w_fc", p["b_fc"], None, None, I, 5, 1, 0)
-                    self._gemm(h, act, p, "w_down", p["b_down"], h, None, H, 3, 1, 0)
+                    self._gemm(wk, act, xn, p, "w_fc", p["b_fc"], None, None, I, 5, 1, 0)
+                    self._gemm(wk, h, act, p, "w_down", p["b_down"], h, None, H, 3, 1, 0)
             return None
         # decode regime: weight-streaming GEMMs write fp32 split-K partials which the NEXT kernel
         # (norm / rope) sums while it reads them anyway — no reduce launches, no bf16 round trip
@@ -264,18 +279,18 @@ class GpuStage:
                 K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
             else:
                 K.norm(xn, h, None, ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
-            self._gemm(qkv, xn, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
+            self._gemm(wk, qkv, xn, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
             K.rope_kvwrite(qkv, ws, sq, p.get("b_qkv"), kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
                            Hq, Hkv, D, llama)
             K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
                               self.scale, splits)
-            self._gemm(h, attn, p, "w_o", None, None, ws, H, 6, so, no)
+            self._gemm(wk, h, attn, p, "w_o", None, None, ws, H, 6, so, no)
             K.norm(xn, h, None, ws, so, p.get("b_o"), p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
             if llama:
-                self._gemm(act, xn, p, "w_gu", None, None, ws, 2 * I, 4, 0, 0)
+                self._gemm(wk, act, xn, p, "w_gu", None, None, ws, 2 * I, 4, 0, 0)
             else:
-                self._gemm(act, xn, p, "w_fc", p["b_fc"], None, ws, I, 5, 0, 0)
-            self._gemm(h, act, p, "w_down", None, None, ws, H, 6, sd, nd)
+                self._gemm(wk, act, xn, p, "w_fc", p["b_fc"], None, ws, I, 5, 0, 0)
+            self._gemm(wk, h, act, p, "w_down", None, None, ws, H, 6, sd, nd)
             pend = (sd, p.get("b_down"))
         return pend
 

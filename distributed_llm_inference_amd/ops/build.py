@@ -20,7 +20,7 @@ ARCH = "gfx950"
 HIP_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-fno-math-errno", "-fno-gpu-rdc",
              "-Wno-unused-result"]
 # kernels with hand-counted vmcnt waits: {source: kernel-name regex}; their ISA is linted after compiling
-LINTED = {"gemm_skinny.hip": "gemm_skinny_kernel"}
+LINTED = {"gemm_skinny.hip": "gemm_skinny_kernel", "gemm_a8w8.hip": "gemm_a8w8_kernel"}
 
 
 def _run(cmd):

@@ -245,6 +245,90 @@ void gemm_w8(Tensor out, const Tensor& x, const Tensor& wp, const Tensor& wscale
   gemm_impl(out, x, wp, wscale, bias, residual, workspace, N, epi, splitk, ntw);
 }
 
+// q[M,K] (uint8, e4m3), scale[M] (fp32) <- x[M,K] (bf16): per-row dynamic quantisation
+void quant_rows(Tensor q, Tensor scale, const Tensor& x) {
+  check_bf16(x, "x"); check_rows(x, "x"); check_dev(q, "q"); check_f32(scale, "scale");
+  const int64_t M = x.size(0), K = x.size(1);
+  DLIA_CHECK(K % 8 == 0, "K must be a multiple of 8");
+  DLIA_CHECK(q.scalar_type() == at::kByte && q.dim() == 2 && q.size(0) >= M && q.size(1) >= K && q.stride(1) == 1,
+             "q must be uint8 [M, K]");
+  DLIA_CHECK(q.stride(0) % 16 == 0 && reinterpret_cast<uintptr_t>(q.data_ptr()) % 16 == 0, "q alignment");
+  DLIA_CHECK(scale.is_contiguous() && scale.numel() >= M, "scale shape");
+  dlia_quant_rows(q.data_ptr(), scale.data_ptr<float>(), x.data_ptr(), (int)M, (int)K, x.stride(0), q.stride(0), cur_stream());
+}
+
+// fp8 x fp8 GEMM: xq uint8 [M,K] + xscale[M], wp from pack_weight_a8w8 + wscale per packed row.
+// More than 256 rows run as 256-row slices (weights re-streamed per slice).
+void gemm_a8w8(Tensor out, const Tensor& xq, const Tensor& xscale, const Tensor& wp, const Tensor& wscale,
+               OptTensor bias, OptTensor residual, OptTensor workspace, int64_t N, int64_t epi, int64_t splitk,
+               int64_t ntw) {
+  check_dev(out, "out"); check_dev(xq, "xq"); check_dev(wp, "wp"); check_f32(xscale, "xscale"); check_f32(wscale, "wscale");
+  DLIA_CHECK(xq.scalar_type() == at::kByte && xq.dim() == 2 && xq.stride(1) == 1, "xq must be uint8 [M, K]");
+  const int64_t M = xq.size(0), K = xq.size(1);
+  DLIA_CHECK(K % 128 == 0, "K must be a multiple of 128");
+  DLIA_CHECK(xq.stride(0) % 16 == 0 && reinterpret_cast<uintptr_t>(xq.data_ptr()) % 16 == 0, "xq alignment");
+  DLIA_CHECK(N % 4 == 0 && epi >= 0 && epi <= 6, "bad N / epilogue");
+  const int64_t n_pad = (N + 127) / 128 * 128;
+  DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == n_pad * K, "packed weight size");
+  DLIA_CHECK(reinterpret_cast<uintptr_t>(wp.data_ptr()) % 16 == 0, "packed weight alignment");
+  DLIA_CHECK(wscale.is_contiguous() && wscale.numel() == n_pad, "wscale must hold one scale per packed row");
+  DLIA_CHECK(xscale.is_contiguous() && xscale.numel() >= M, "xscale shape");
+  const int64_t n_out = epi == 4 ? N / 2 : N;
+  if (epi == 4) DLIA_CHECK(N % 32 == 0, "swiglu needs gate/up tile pairs");
+  const bool f32 = out.scalar_type() == at::kFloat;
+  DLIA_CHECK(f32 || out.scalar_type() == at::kBFloat16, "out must be bf16 or fp32");
+  DLIA_CHECK(epi == 6 || (out.dim() == 2 && out.stride(1) == 1 && out.size(0) >= M && out.size(1) >= n_out), "out shape");
+  DLIA_CHECK(out.stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0, "out alignment");
+  const void* bp = nullptr; const void* rp = nullptr; long ldr = 0;
+  if (epi == 1 || epi == 3 || epi == 5) {
+    DLIA_CHECK(bias.has_value(), "epilogue needs bias");
+    check_bf16(*bias, "bias");
+    DLIA_CHECK(bias->is_contiguous() && bias->numel() >= n_out, "bias shape");
+    bp = bias->data_ptr();
+  }
+  if (epi == 2 || epi == 3) {
+    DLIA_CHECK(residual.has_value(), "epilogue needs residual");
+    check_bf16(*residual, "residual"); check_rows(*residual, "residual");
+    DLIA_CHECK(residual->size(0) >= M && residual->size(1) >= n_out, "residual shape");
+    rp = residual->data_ptr(); ldr = residual->stride(0);
+  }
+  auto stream = cur_stream();
+  if (M <= 256) {
+    float* ws = nullptr;
+    int sk = (int)splitk;
+    if (sk <= 0) {
+      int an, as;
+      dlia_gemm_skinny_config((int)M, (int)N, (int)K, (int)epi, workspace.has_value() ? 1 : 0, &an, &as);
+      sk = as;
+    }
+    if (workspace.has_value()) {
+      check_f32(*workspace, "workspace");
+      const int64_t have = workspace->numel();
+      if (epi == 6) {
+        DLIA_CHECK(have >= (int64_t)sk * M * N, "gemm: partial workspace smaller than [splitk, M, N]");
+      } else {
+        while (sk > 1 && have < (int64_t)sk * M * N) sk /= 2;
+      }
+      ws = workspace->data_ptr<float>();
+    } else {
+      DLIA_CHECK(epi != 6, "partial output needs a workspace");
+      sk = 1;
+    }
+    dlia_gemm_a8w8(out.data_ptr(), xq.data_ptr(), xscale.data_ptr<float>(), wp.data_ptr(), wscale.data_ptr<float>(), bp, rp,
+                   ws, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, (int)ntw, stream);
+  } else {
+    DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
+    const int64_t osz = out.element_size();
+    for (int64_t m0 = 0; m0 < M; m0 += 256) {
+      const int64_t mm = std::min<int64_t>(256, M - m0);
+      const char* rps = rp ? (const char*)rp + m0 * ldr * 2 : nullptr;
+      dlia_gemm_a8w8((char*)out.data_ptr() + m0 * out.stride(0) * osz, (const char*)xq.data_ptr() + m0 * xq.stride(0),
+                     xscale.data_ptr<float>() + m0, wp.data_ptr(), wscale.data_ptr<float>(), bp, rps, nullptr, (int)mm,
+                     (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, 1, 2, stream);
+    }
+  }
+}
+
 int64_t gemm_splitk(int64_t M, int64_t N, int64_t K) { return dlia_gemm_skinny_splitk((int)M, (int)N, (int)K); }
 
 // [ntw, splitk] the weight-streaming kernel would use for this shape
@@ -338,6 +422,8 @@ TORCH_LIBRARY(dlia, m) {
   m.def("rope_kvwrite(Tensor(a!) qkv, Tensor? partial, int splits, Tensor? pbias, Tensor(b!) kv_cache, Tensor cos, Tensor sin, Tensor tok_pos, Tensor tok_seq, Tensor block_table, int Hq, int Hkv, int D, bool use_rope) -> ()");
   m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
   m.def("gemm_w8(Tensor(a!) out, Tensor x, Tensor wp, Tensor wscale, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
+  m.def("gemm_a8w8(Tensor(a!) out, Tensor xq, Tensor xscale, Tensor wp, Tensor wscale, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
+  m.def("quant_rows(Tensor(a!) q, Tensor(b!) scale, Tensor x) -> ()");
   m.def("gemm_config(int M, int N, int K, int epi, bool allow_split) -> int[]");
   m.def("gemm_splitk(int M, int N, int K) -> int");
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
@@ -352,6 +438,8 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
   m.impl("rope_kvwrite", &rope_kvwrite);
   m.impl("gemm", &gemm);
   m.impl("gemm_w8", &gemm_w8);
+  m.impl("gemm_a8w8", &gemm_a8w8);
+  m.impl("quant_rows", &quant_rows);
   m.impl("paged_attention", &paged_attention);
   m.impl("sample", &sample);
   m.impl("advance", &advance);

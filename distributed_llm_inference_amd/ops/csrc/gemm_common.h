@@ -9,6 +9,7 @@ struct GemmParams {
   const bf16* x; long ldx;
   const u32x4* wp;            // packed weights (bf16 fragments, or fp8 e4m3 with two k-steps per 16 B)
   const float* wscale;        // fp8 weights: per packed row (GEMM column) dequantisation scale; else null
+  const float* xscale;        // fp8 activations: per row dequantisation scale (x then points at e4m3 bytes)
   void* out; long ldo;
   const bf16* bias;           // per output column (pre-activation), may be null
   const bf16* residual; long ldr;
@@ -52,6 +53,59 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
   store4(p.out, p.ldo, m, n, g, p.out_f32);
 }
 
+
+// Output stage shared by the streaming kernels: acc[i][j][r] = C[m = i*16 + l15][n = (tile0+j)*16 + quad*4 + r].
+// Writes fp32 partials (split-K or partial-only), or applies the fused epilogue.
+template <int MT, int NTW>
+__device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc)[MT][NTW], int tile0, int l15,
+                                                int quad, int ks) {
+  if (p.partial_only || p.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = (tile0 + j) * 16 + quad * 4;
+        if (n < p.N) *reinterpret_cast<f32x4*>(p.partial + ((long)ks * p.M + m) * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = i * 16 + l15;
+    if (m >= p.M) continue;
+    if (p.act == 1) {
+      // tiles (2t, 2t+1) = (gate, up) rows of output columns [16t, 16t+16)
+      if constexpr (NTW >= 2) {
+#pragma unroll
+        for (int j = 0; j < NTW; j += 2) {
+          const int n = ((tile0 + j) >> 1) * 16 + quad * 4;
+          if (n < (p.N >> 1)) {
+            float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const float u[4] = {acc[i][j + 1][0], acc[i][j + 1][1], acc[i][j + 1][2], acc[i][j + 1][3]};
+            epilogue4(p, m, n, g, u);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = (tile0 + j) * 16 + quad * 4;
+        if (n < p.N) {
+          float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          epilogue4(p, m, n, g, g);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace dlia
+extern "C" void dlia_splitk_reduce(const dlia::GemmParams* p, hipStream_t stream);
+extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_split, int* ntw_out, int* splitk_out);
+namespace dlia {
 
 // Packing pads N to a multiple of 128 columns (8 n-tiles), so any (waves x tiles) tiling divides it.
 static inline int packed_ntiles(int N) { return ((N + 127) / 128) * 8; }

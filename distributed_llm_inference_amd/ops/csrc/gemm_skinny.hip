@@ -533,6 +533,13 @@ extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_
   *ntw_out = ntw; *splitk_out = s;
 }
 
+// Sum the split-K partials of `p` and apply its epilogue (used by every streaming GEMM variant).
+extern "C" void dlia_splitk_reduce(const dlia::GemmParams* p, hipStream_t stream) {
+  const int nout = p->act == 1 ? p->N / 2 : p->N;
+  const long work = (long)p->M * (nout / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, *p);
+}
+
 extern "C" int dlia_gemm_skinny_splitk(int M, int N, int K) {
   int ntw, s;
   dlia_gemm_skinny_config(M, N, K, 0, 1, &ntw, &s);
@@ -547,7 +554,7 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
                                  int out_f32, int splitk, int ntw, hipStream_t stream) {
   if (M <= 0 || N <= 0) return;
   GemmParams p;
-  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = wscale; p.out = out; p.ldo = ldo;
+  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = wscale; p.xscale = nullptr; p.out = out; p.ldo = ldo;
   p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;
   p.residual = (epi == 2 || epi == 3) ? (const bf16*)residual : nullptr;
   p.ldr = ldr; p.partial = workspace; p.M = M; p.N = N; p.K = K;
@@ -569,9 +576,5 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
   else if (M <= 64) launch_skinny_ntw<4>(p, ntw, stream);
   else if (M <= 128) launch_skinny_ntw<8>(p, ntw, stream);
   else               launch_skinny_ntw<16>(p, ntw, stream);
-  if (splitk > 1 && !p.partial_only) {
-    const int nout = p.act == 1 ? N / 2 : N;
-    const long work = (long)M * (nout / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, p);
-  }
+  if (splitk > 1 && !p.partial_only) dlia_splitk_reduce(&p, stream);
 }

@@ -142,7 +142,7 @@ extern "C" void dlia_gemm_tile(void* out, const void* x, const void* wp, const v
                                int epi, int out_f32, hipStream_t stream) {
   if (M <= 0 || N <= 0) return;
   GemmParams p;
-  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = nullptr; p.out = out; p.ldo = ldo;
+  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = nullptr; p.xscale = nullptr; p.out = out; p.ldo = ldo;
   p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;
   p.residual = (epi == 2 || epi == 3) ? (const bf16*)residual : nullptr;
   p.ldr = ldr; p.partial = nullptr; p.M = M; p.N = N; p.K = K;

@@ -43,6 +43,15 @@ void dlia_gemm_skinny(void* out, const void* x, const void* wp, const void* bias
 void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_split, int* ntw_out, int* splitk_out);
 int dlia_gemm_skinny_splitk(int M, int N, int K);
 
+// ---- gemm_a8w8.hip --------------------------------------------------------------------
+// fp8 x fp8 streaming GEMM on the block-scaled MFMA (M <= 256): xq = e4m3 bytes [M,K] with per-row
+// scales, wp = pack_weight_a8w8 image with per-column scales. Epilogues as dlia_gemm_skinny.
+void dlia_gemm_a8w8(void* out, const void* xq, const float* xscale, const void* wp, const float* wscale,
+                    const void* bias, const void* residual, float* workspace, int M, int N, int K,
+                    long ldx, long ldo, long ldr, int epi, int out_f32, int splitk, int ntw, hipStream_t stream);
+// per-row dynamic e4m3 quantisation of bf16 activations: q[M,K] bytes (row stride ldq), scale[M]
+void dlia_quant_rows(void* q, float* scale, const void* x, int M, int K, long ldx, long ldq, hipStream_t stream);
+
 // ---- gemm_tile.hip --------------------------------------------------------------------
 // Same contract for large M (prefill): 128x128x64 LDS-staged MFMA tiles.
 void dlia_gemm_tile(void* out, const void* x, const void* wp, const void* bias,

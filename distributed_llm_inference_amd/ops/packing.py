@@ -80,6 +80,29 @@ def unpack_weight_fp8(wp: torch.Tensor, scale: torch.Tensor, N: int, K: int) -> 
     return dequantize_fp8(v, scale)[:N].contiguous()
 
 
+def pack_weight_a8w8(w: torch.Tensor):
+    """[N, K] -> (packed e4m3 image, fp32 scales [padded_n(N)]) for the fp8 x fp8 kernel.
+
+    The block-scaled MFMA takes 128 K-elements per instruction: lane l = quad*16 + n holds
+    W[nt*16 + n][kc*128 + quad*32 .. +32] as 32 bytes. They are stored as two 16-byte halves in
+    separate 1 KiB planes, [n-tile][K/128][half][64 lanes][16 B], so each ring load is contiguous."""
+    N, K = w.shape
+    if K % PACK_K:
+        raise ValueError(f"K={K} must be a multiple of {PACK_K}")
+    q, scale = quantize_fp8(w)
+    Np = padded_n(N)
+    if Np != N:
+        q = torch.cat([q, q.new_zeros(Np - N, K)], dim=0)
+        scale = torch.cat([scale, scale.new_ones(Np - N)])
+    v = q.reshape(Np // 16, 16, K // 128, 4, 2, 16)       # [nt, n, kc, quad, half, b]
+    return v.permute(0, 2, 4, 3, 1, 5).contiguous().reshape(-1), scale.contiguous()
+
+
+def quantize_rows_fp8(x: torch.Tensor):
+    """Reference of the device row quantiser: [M, K] -> (e4m3 bytes [M, K], fp32 scale [M])."""
+    return quantize_fp8(x)
+
+
 def interleave_gate_up(w_gate: torch.Tensor, w_up: torch.Tensor) -> torch.Tensor:
     """[I,H],[I,H] -> [2I,H] whose 16-row tiles alternate gate, up: the wave that owns tiles
     (2t, 2t+1) then holds gate and up of the same 16 output columns in identical fragment

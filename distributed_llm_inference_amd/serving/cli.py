@@ -20,7 +20,7 @@ from ..config import EngineConfig
 def _add_engine_args(ap):
     ap.add_argument("--config", help="YAML file with EngineConfig fields")
     ap.add_argument("--model")
-    ap.add_argument("--dtype", choices=["bf16", "fp8", "fp32"], help="fp8 = e4m3 layer weights with per-channel scales")
+    ap.add_argument("--dtype", choices=["bf16", "fp8", "fp8w", "fp32"], help="fp8 = layer GEMMs on the fp8 MFMA; fp8w = e4m3 weights only")
     ap.add_argument("--pp-size", type=int)
     ap.add_argument("--partition", choices=["balanced", "even", "explicit"])
     ap.add_argument("--layer-ranges", help='explicit ranges, e.g. "0-11,11-22"')

@@ -188,6 +188,88 @@ def test_fp8_quantisation_error_is_bounded(K):
     assert (a - b).abs().max().item() < 0.06 * a.abs().max().item()
 
 
+def test_quant_rows_matches_reference(K):
+    torch.manual_seed(2)
+    x = bf(torch.randn(37, 1024, device=DEV) * (1 + torch.arange(37, device=DEV).view(-1, 1)))
+    x[5] = 0
+    q = torch.zeros(37, 1024, device=DEV, dtype=torch.uint8)
+    sc = torch.zeros(37, device=DEV)
+    K.quant_rows(q, sc, x)
+    q_ref, s_ref = packing.quantize_rows_fp8(x)
+    assert_close(sc, s_ref, 1e-6, 1e-5, "row scales")
+    deq, deq_ref = packing.dequantize_fp8(q, sc), packing.dequantize_fp8(q_ref, s_ref)
+    # device and torch may round an exact tie differently: compare dequantised values within one e4m3 step
+    assert ((deq - deq_ref).abs() <= 0.0626 * deq_ref.abs() + 1e-6).all()
+    assert (deq[5] == 0).all()
+
+
+def _gemm_a8w8_case(K, M, N, Kd, epi, splitk, out_f32=False, seed=0, ntw=0):
+    """fp8 x fp8 on the block-scaled MFMA against the fp32 product of the DEQUANTISED operands:
+    products of e4m3 values are exact in fp32, so only accumulation order differs."""
+    torch.manual_seed(seed)
+    x = bf(torch.randn(M, Kd, device=DEV) * (1 + torch.arange(M, device=DEV).view(-1, 1) % 5))
+    xq = torch.zeros(M, Kd, device=DEV, dtype=torch.uint8)
+    xs = torch.zeros(M, device=DEV)
+    K.quant_rows(xq, xs, x)
+    x_ref = packing.dequantize_fp8(xq, xs)
+    if epi == 4:
+        wg = torch.randn(N // 2, Kd, device=DEV) / math.sqrt(Kd)
+        wu = torch.randn(N // 2, Kd, device=DEV) / math.sqrt(Kd)
+        wp, sc = packing.pack_weight_a8w8(packing.interleave_gate_up(wg, wu))
+        w_ref = torch.cat([packing.dequantize_fp8(*packing.quantize_fp8(wg)), packing.dequantize_fp8(*packing.quantize_fp8(wu))], 0)
+        n_out = N // 2
+    else:
+        w = torch.randn(N, Kd, device=DEV) / math.sqrt(Kd) * (1 + torch.arange(N, device=DEV).view(-1, 1) % 7)
+        wp, sc = packing.pack_weight_a8w8(w)
+        w_ref = packing.dequantize_fp8(*packing.quantize_fp8(w))
+        n_out = N
+    bias = bf(torch.randn(n_out, device=DEV))
+    res = bf(torch.randn(M, n_out, device=DEV))
+    ws = torch.full((16 * max(M, 128) * N,), float("nan"), device=DEV, dtype=torch.float32) if (splitk != 1 or epi == 6) else None
+    if epi == 6:
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        K.gemm_a8w8(out, xq, xs, wp, sc, None, None, ws, N, 6, splitk, ntw)
+        S = splitk if splitk > 0 else int(K.gemm_config(M, N, Kd, 6, True)[1])
+        got = ws[:S * M * N].view(S, M, N).sum(0)
+        assert_close(got, x_ref @ w_ref.t(), 2e-3, 2e-3, f"a8w8 partials M={M} N={N} K={Kd} S={S}")
+        return
+    out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    K.gemm_a8w8(out, xq, xs, wp, sc, bias, res, ws, N, epi, splitk, ntw)
+    want = ref.gemm(x_ref, w_ref, bias, res, epi)
+    assert_close(out, want, 3e-2 if not out_f32 else 2e-3, 2e-2 if not out_f32 else 2e-3,
+                 f"gemm_a8w8 M={M} N={N} K={Kd} epi={epi} splitk={splitk}")
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("epi", [0, 3, 4, 5, 6])
+def test_gemm_a8w8_epilogues(K, M, epi):
+    _gemm_a8w8_case(K, M, 512, 256, epi, 1, out_f32=(epi == 0))
+    _gemm_a8w8_case(K, M, 2048, 1024, epi, 0 if epi != 6 else 4)
+
+
+@pytest.mark.parametrize("chunks", [1, 2, 3, 4, 5, 6, 7, 9])
+def test_gemm_a8w8_ring_prefetch_edges(K, chunks):
+    for M in (8, 100, 256):
+        for ntw in (1, 2):
+            _gemm_a8w8_case(K, M, 2048, 128 * chunks, 0, 1, out_f32=True, ntw=ntw)
+
+
+def test_gemm_a8w8_layout_identity_and_slices(K):
+    """Asymmetric exact-integer operands (every value an exact e4m3 number) pin the operand and
+    accumulator maps; 600 rows exercise the 256-row slicing."""
+    Kd, N = 256, 256
+    x = bf(((torch.arange(64, device=DEV).view(-1, 1) * 3 + torch.arange(Kd, device=DEV).view(1, -1)) % 9).float())
+    w = ((torch.arange(N, device=DEV).view(-1, 1) * 5 + torch.arange(Kd, device=DEV).view(1, -1) * 2) % 7).float()
+    xq = torch.zeros(64, Kd, device=DEV, dtype=torch.uint8); xs = torch.zeros(64, device=DEV)
+    K.quant_rows(xq, xs, x)
+    wp, sc = packing.pack_weight_a8w8(w)
+    out = torch.empty(64, N, device=DEV, dtype=torch.float32)
+    K.gemm_a8w8(out, xq, xs, wp, sc, None, None, None, N, 0, 1, 0)
+    want = packing.dequantize_fp8(xq, xs) @ packing.dequantize_fp8(*packing.quantize_fp8(w)).t()
+    assert_close(out, want, 1e-3, 1e-4, "a8w8 integer operands")
+    _gemm_a8w8_case(K, 600, 1024, 512, 3, 1)
+
+
 def test_gemm_layout_identity(K):
     """A = I with an ASYMMETRIC B: catches a transposed accumulator map that random-vs-random
     tolerance checks could hide."""

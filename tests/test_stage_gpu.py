@@ -123,18 +123,19 @@ def test_graph_decode_split_stage_hidden_handoff():
         assert torch.equal(tf, t2), f"step {i}"
 
 
-def test_fp8_weight_stage_tracks_bf16_stage():
+@pytest.mark.parametrize("mode", ["fp8", "fp8w"])
+def test_fp8_weight_stage_tracks_bf16_stage(mode):
     """fp8 (e4m3 + per-channel scale) layer weights: logits stay close to the bf16-weight stage,
     prefill (sliced streaming GEMMs over > 128 rows), eager decode and graph decode."""
     from distributed_llm_inference_amd.models.stage_gpu import GpuStage
     spec = gpu_spec("llama")
     plan = make_plans(spec, 1)[0]
     mk = lambda wd: GpuStage(spec, plan, random_stage_weights(spec, plan, seed=5, dtype=torch.bfloat16), max_slots=8,
-                             max_seq_len=256, num_blocks=64, max_tokens=256, max_batch=8, weight_dtype=wd)
-    a, b = mk("bf16"), mk("fp8")
+                             max_seq_len=256, num_blocks=64, max_tokens=320, max_batch=8, weight_dtype=wd)
+    a, b = mk("bf16"), mk(mode)
     assert b.memory_report()["weights_gib"] < 0.75 * a.memory_report()["weights_gib"]
     g = torch.Generator().manual_seed(0)
-    lens = [150, 20]                      # 170 tokens: the > 128-row path
+    lens = [230, 70]                      # 300 tokens: the sliced (> 256-row) path
     toks = torch.randint(3, spec.vocab_size, (sum(lens),), generator=g).tolist()
     tables = {0: list(range(0, 8)), 1: list(range(8, 16))}
     d = step([0, 1], lens, [0, 0], toks, tables=tables)
