@@ -201,6 +201,9 @@ class GpuStage:
             self.K.gemm(out, x, p[name], bias, residual, ws, N, epi, splitk, ntw)
         elif self.wmode == "fp8w":
             self.K.gemm_w8(out, x, p[name], sc, bias, residual, ws, N, epi, splitk, ntw)
+        elif x is None:          # the preceding norm already wrote the e4m3 rows and their scales
+            xq = wk.xq[:out.shape[0], :self.spec.hidden_size]
+            self.K.gemm_a8w8(out, xq, wk.xs, p[name], sc, bias, residual, ws, N, epi, splitk, min(ntw, 2))
         else:
             T, Kd = x.shape
             xq = wk.xq[:T, :Kd]
@@ -247,23 +250,33 @@ class GpuStage:
         partial = wk.attn_ws if splits > 1 else None
         llama = s.is_llama
         nmode = 0 if llama else 1
+        fp8 = self.wmode == "fp8"
+
+        def norm(part, S, pbias, w, b):
+            """Pre-GEMM norm. In fp8 mode its output is already the GEMM's e4m3 input (returns None)."""
+            if fp8:
+                K.norm_q(wk.xq[:T, :H], wk.xs, h, None, part, S, pbias, w, b, s.norm_eps, nmode)
+                return None
+            K.norm(xn, h, None, part, S, pbias, w, b, None, s.norm_eps, nmode)
+            return xn
+
         if T > DECODE_ROWS:
             # prefill regime: tiled MFMA GEMMs with fused bias / residual / activation epilogues
             for li, p in enumerate(self.layers):
                 kv = self.kv[li]
-                K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
-                self._gemm(wk, qkv, xn, p, "w_qkv", p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
+                x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
+                self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
                 K.rope_kvwrite(qkv, None, 1, None, kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
                                Hq, Hkv, D, llama)
                 K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
                                   self.scale, splits)
                 self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
-                K.norm(xn, h, None, None, 1, None, p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
+                x2 = norm(None, 1, None, p["ln2_w"], p.get("ln2_b"))
                 if llama:
-                    self._gemm(wk, act, xn, p, "w_gu", None, None, None, 2 * I, 4, 1, 0)
+                    self._gemm(wk, act, x2, p, "w_gu", None, None, None, 2 * I, 4, 1, 0)
                     self._gemm(wk, h, act, p, "w_down", None, h, None, H, 2, 1, 0)
                 else:
-                    self._gemm(wk, act, xn, p, "w_fc", p["b_fc"], None, None, I, 5, 1, 0)
+                    self._gemm(wk, act, x2, p, "w_fc", p["b_fc"], None, None, I, 5, 1, 0)
                     self._gemm(wk, h, act, p, "w_down", p["b_down"], h, None, H, 3, 1, 0)
             return None
         # decode regime: weight-streaming GEMMs write fp32 split-K partials which the NEXT kernel
@@ -276,20 +289,20 @@ class GpuStage:
         for li, p in enumerate(self.layers):
             kv = self.kv[li]
             if pend is None:
-                K.norm(xn, h, None, None, 1, None, p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
+                x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
             else:
-                K.norm(xn, h, None, ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"), None, s.norm_eps, nmode)
-            self._gemm(wk, qkv, xn, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
+                x1 = norm(ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"))
+            self._gemm(wk, qkv, x1, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
             K.rope_kvwrite(qkv, ws, sq, p.get("b_qkv"), kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
                            Hq, Hkv, D, llama)
             K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
                               self.scale, splits)
             self._gemm(wk, h, attn, p, "w_o", None, None, ws, H, 6, so, no)
-            K.norm(xn, h, None, ws, so, p.get("b_o"), p["ln2_w"], p.get("ln2_b"), None, s.norm_eps, nmode)
+            x2 = norm(ws, so, p.get("b_o"), p["ln2_w"], p.get("ln2_b"))
             if llama:
-                self._gemm(wk, act, xn, p, "w_gu", None, None, ws, 2 * I, 4, 0, 0)
+                self._gemm(wk, act, x2, p, "w_gu", None, None, ws, 2 * I, 4, 0, 0)
             else:
-                self._gemm(wk, act, xn, p, "w_fc", p["b_fc"], None, ws, I, 5, 0, 0)
+                self._gemm(wk, act, x2, p, "w_fc", p["b_fc"], None, ws, I, 5, 0, 0)
             self._gemm(wk, h, act, p, "w_down", None, None, ws, H, 6, sd, nd)
             pend = (sd, p.get("b_down"))
         return pend

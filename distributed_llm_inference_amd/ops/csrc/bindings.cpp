@@ -43,10 +43,19 @@ inline void check_rows(const Tensor& t, const char* name) {
 }
 
 // out[r,:] = norm(x[row_idx[r] or r,:] (+addend -> x)) * w (+ b); mode 0 rms, 1 layernorm, 2 fold only.
-void norm(Tensor out, Tensor x, OptTensor delta, OptTensor partial, int64_t splits, OptTensor pbias,
-          const Tensor& w, OptTensor b, OptTensor row_idx, double eps, int64_t mode) {
-  check_bf16(out, "out"); check_bf16(x, "x"); check_bf16(w, "w");
+static void norm_impl(Tensor out, Tensor x, OptTensor delta, OptTensor partial, int64_t splits, OptTensor pbias,
+                      const Tensor& w, OptTensor b, OptTensor row_idx, double eps, int64_t mode, OptTensor qscale) {
+  check_bf16(x, "x"); check_bf16(w, "w");
   check_rows(out, "out"); check_rows(x, "x");
+  float* qs = nullptr;
+  if (qscale.has_value()) {
+    check_f32(*qscale, "qscale");
+    DLIA_CHECK(out.scalar_type() == at::kByte && out.stride(0) % 16 == 0, "quantised norm output must be uint8 rows");
+    DLIA_CHECK(mode != 2, "fold-only norm has no output to quantise");
+    qs = qscale->data_ptr<float>();
+  } else {
+    check_bf16(out, "out");
+  }
   const int64_t H = x.size(1);
   DLIA_CHECK(H % 8 == 0, "hidden size must be a multiple of 8");
   DLIA_CHECK(mode >= 0 && mode <= 2, "norm mode");
@@ -59,6 +68,7 @@ void norm(Tensor out, Tensor x, OptTensor delta, OptTensor partial, int64_t spli
     ridx = row_idx->data_ptr<int>();
   }
   DLIA_CHECK(out.size(0) >= rows, "norm: out has too few rows");
+  if (qs) DLIA_CHECK(qscale->is_contiguous() && qscale->numel() >= rows, "qscale shape");
   const void* dp = nullptr;
   if (delta.has_value()) {
     check_bf16(*delta, "delta"); check_rows(*delta, "delta");
@@ -86,7 +96,18 @@ void norm(Tensor out, Tensor x, OptTensor delta, OptTensor partial, int64_t spli
     bp = b->data_ptr();
   }
   dlia_norm(out.data_ptr(), x.data_ptr(), dp, pp, (int)splits, pM, pb, w.data_ptr(), bp, ridx, (int)rows, (int)H,
-            x.stride(0), out.stride(0), (float)eps, (int)mode, cur_stream());
+            x.stride(0), out.stride(0), (float)eps, (int)mode, qs, cur_stream());
+}
+
+void norm(Tensor out, Tensor x, OptTensor delta, OptTensor partial, int64_t splits, OptTensor pbias,
+          const Tensor& w, OptTensor b, OptTensor row_idx, double eps, int64_t mode) {
+  norm_impl(out, x, delta, partial, splits, pbias, w, b, row_idx, eps, mode, c10::nullopt);
+}
+
+// norm whose output is e4m3 bytes + per-row scale (input of gemm_a8w8)
+void norm_q(Tensor out_q, Tensor qscale, Tensor x, OptTensor delta, OptTensor partial, int64_t splits, OptTensor pbias,
+            const Tensor& w, OptTensor b, double eps, int64_t mode) {
+  norm_impl(out_q, x, delta, partial, splits, pbias, w, b, c10::nullopt, eps, mode, qscale);
 }
 
 void embed(Tensor out, const Tensor& ids, OptTensor pos, const Tensor& wte, OptTensor wpe) {
@@ -423,6 +444,7 @@ TORCH_LIBRARY(dlia, m) {
   m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
   m.def("gemm_w8(Tensor(a!) out, Tensor x, Tensor wp, Tensor wscale, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
   m.def("gemm_a8w8(Tensor(a!) out, Tensor xq, Tensor xscale, Tensor wp, Tensor wscale, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
+  m.def("norm_q(Tensor(a!) out_q, Tensor(b!) qscale, Tensor(c!) x, Tensor? delta, Tensor? partial, int splits, Tensor? pbias, Tensor w, Tensor? b, float eps, int mode) -> ()");
   m.def("quant_rows(Tensor(a!) q, Tensor(b!) scale, Tensor x) -> ()");
   m.def("gemm_config(int M, int N, int K, int epi, bool allow_split) -> int[]");
   m.def("gemm_splitk(int M, int N, int K) -> int");
@@ -440,6 +462,7 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
   m.impl("gemm_w8", &gemm_w8);
   m.impl("gemm_a8w8", &gemm_a8w8);
   m.impl("quant_rows", &quant_rows);
+  m.impl("norm_q", &norm_q);
   m.impl("paged_attention", &paged_attention);
   m.impl("sample", &sample);
   m.impl("advance", &advance);

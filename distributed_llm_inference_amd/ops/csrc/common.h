@@ -43,6 +43,18 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
   return r;
 }
 
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane_id() == 0) scratch[w] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, scratch[i]);
+  return r;
+}
+
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 // streamed-once data (weights in decode): non-temporal so it does not displace reusable lines

@@ -30,7 +30,6 @@ namespace dlia {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kA8Threads = 256;
-constexpr int kA8BK = 128;           // K elements (= bytes) per chunk
 
 template <int V> struct IntA { static constexpr int value = V; };
 
@@ -53,25 +52,32 @@ __device__ __forceinline__ const void* a8_sel_ptr(bool c, const void* a, const v
   return reinterpret_cast<const char*>(b) + (d & -static_cast<long>(c));
 }
 
-// MT in {4, 8, 16} (64 / 128 / 256 rows), NTW in {1, 2}.
-template <int MT, int NTW>
+// MT in {4, 8, 16} (64 / 128 / 256 rows), NTW in {1, 2}, KSUB = MFMA k-steps (128 elements each)
+// per chunk: 2 up to 128 rows — twice the weight bytes in flight per wave, which is what a
+// memory-bound launch needs — and 1 at 256 rows, where two 64 KiB x stages would leave room for
+// only one workgroup per CU.
+template <int MT, int NTW, int KSUB>
 __global__ __launch_bounds__(kA8Threads, 2) void gemm_a8w8_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of MT*16 rows x 128 B
-  constexpr int ROWB = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages of MT*16 rows x ROWB bytes
+  constexpr int ROWB = 128 * KSUB;
+  constexpr int BKE = 128 * KSUB;                // K elements per chunk
   constexpr int kStageBytes = MT * 16 * ROWB;
-  constexpr int XL = MT * 16 / 8 / 4;            // DMA instructions (8 rows each) per wave and chunk
+  constexpr int RPI = 1024 / ROWB;               // rows per DMA instruction
+  constexpr int LPR = ROWB / 16;                 // 16-B slots per row
+  constexpr int XL = MT * 16 / RPI / 4;          // DMA instructions per wave and chunk
+  constexpr int HL = 2 * KSUB;                   // 16-B ring loads per n-tile and chunk
   static_assert(XL >= 1, "at least 64 rows");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, quad = lane >> 4;
   const int nblk = blockIdx.x, ks = blockIdx.y;
-  const int KC = p.K / kA8BK;                    // chunks in K
+  const int KC = p.K / BKE;                      // chunks in K
   const int cper = (KC + p.splitk - 1) / p.splitk;
   const int c0 = ks * cper;
   const int c1 = min(KC, c0 + cper);
   const int n = c1 - c0;
   const int tile0 = (nblk * 4 + wave) * NTW;
   const bool wave_active = tile0 < p.ntiles;
-  auto swz = [](int row) { return (row >> 1) & 7; };
+  auto swz = [](int row) { return KSUB == 1 ? ((row >> 1) & 7) : (row & 15); };
 
   const unsigned char* xq = reinterpret_cast<const unsigned char*>(p.x);
   const void* const dummy = p.x;
@@ -80,16 +86,16 @@ __global__ __launch_bounds__(kA8Threads, 2) void gemm_a8w8_kernel(GemmParams p) 
   auto xdma = [&](int stage, int c) {
 #pragma unroll
     for (int q = 0; q < XL; ++q) {
-      const int row = 8 * (wv * XL + q) + (lane >> 3);
-      const unsigned char* src = xq + (long)(row < p.M ? row : p.M - 1) * p.ldx + (((lane & 7) ^ swz(row)) << 4) +
-                                 (long)(c0 + c) * kA8BK;
+      const int row = RPI * (wv * XL + q) + lane / LPR;
+      const unsigned char* src = xq + (long)(row < p.M ? row : p.M - 1) * p.ldx + (((lane % LPR) ^ swz(row)) << 4) +
+                                 (long)(c0 + c) * BKE;
       a8_gload_lds16(src, lds0 + stage * kStageBytes + (wv * XL + q) * 1024);
     }
   };
   const u32x4* wbase[NTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
-    wbase[j] = p.wp + ((long)(wave_active ? tile0 + j : 0) * KC + c0) * 2 * 64 + lane;
+    wbase[j] = p.wp + ((long)(wave_active ? tile0 + j : 0) * KC + c0) * HL * 64 + lane;
 
   f32x4 acc[MT][NTW];
 #pragma unroll
@@ -103,19 +109,19 @@ __global__ __launch_bounds__(kA8Threads, 2) void gemm_a8w8_kernel(GemmParams p) 
     // together, so the wait is on the younger half:
     //   w(c) has x(c), w(c+1), x(c+1) younger at its use      -> vmcnt(2 XL + 2 NTW)
     //   x(c+1) has w(c+2) younger at the end of chunk c        -> vmcnt(2 NTW)
-    constexpr int kWaitW = 2 * XL + 2 * NTW, kWaitX = 2 * NTW;
+    constexpr int kWaitW = 2 * XL + HL * NTW, kWaitX = HL * NTW;     // (HL = 2 halves x KSUB k-steps)
     static_assert(kWaitW <= 63, "vmcnt is a 6-bit counter");
-    u32x4 w[2][2][NTW];                            // [chunk parity][half][n-tile]
+    u32x4 w[2][HL][NTW];                           // [chunk parity][k-step * 2 + half][n-tile]
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < HL; ++h)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) a8_gload16_nt(w[0][h][j], wbase[j] + (long)h * 64);
     xdma(0, 0);
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < HL; ++h)
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
-        a8_gload16_nt(w[1][h][j], a8_sel_ptr(n > 1, wbase[j] + (long)(2 + h) * 64, dummy));
+        a8_gload16_nt(w[1][h][j], a8_sel_ptr(n > 1, wbase[j] + (long)(HL + h) * 64, dummy));
     a8_wait_vm<kWaitX>();                          // x(0) in LDS; w(1) may still fly
     __syncthreads();
 
@@ -124,35 +130,38 @@ __global__ __launch_bounds__(kA8Threads, 2) void gemm_a8w8_kernel(GemmParams p) 
       xdma(par ^ 1, min(c + 1, n - 1));
       const char* xb = smem + par * kStageBytes;
       a8_wait_vm<kWaitW>();
-      i32x8 wf[NTW];
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const u32x4 lo = w[par][0][j], hi = w[par][1][j];
-        wf[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-      }
+      for (int kq = 0; kq < KSUB; ++kq) {
+        i32x8 wf[NTW];
 #pragma unroll
-      for (int ig = 0; ig < MT / 4; ++ig) {
-        i32x8 xf[4];
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-          const char* rowp = xb + ((ig * 4 + i4) * 16 + l15) * ROWB;
-          const u32x4 lo = *reinterpret_cast<const u32x4*>(rowp + (((2 * quad) ^ swz(l15)) << 4));
-          const u32x4 hi = *reinterpret_cast<const u32x4*>(rowp + (((2 * quad + 1) ^ swz(l15)) << 4));
-          xf[i4] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        for (int j = 0; j < NTW; ++j) {
+          const u32x4 lo = w[par][2 * kq][j], hi = w[par][2 * kq + 1][j];
+          wf[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
         }
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4)
+        for (int ig = 0; ig < MT / 4; ++ig) {
+          i32x8 xf[4];
 #pragma unroll
-          for (int j = 0; j < NTW; ++j)
-            acc[ig * 4 + i4][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                wf[j], xf[i4], acc[ig * 4 + i4][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int i4 = 0; i4 < 4; ++i4) {
+            const char* rowp = xb + ((ig * 4 + i4) * 16 + l15) * ROWB;
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(rowp + (((kq * 8 + 2 * quad) ^ swz(l15)) << 4));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(rowp + (((kq * 8 + 2 * quad + 1) ^ swz(l15)) << 4));
+            xf[i4] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+          }
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+              acc[ig * 4 + i4][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                  wf[j], xf[i4], acc[ig * 4 + i4][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < HL; ++h)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
-          a8_gload16_nt(w[par][h][j], a8_sel_ptr(c + 2 < n, wbase[j] + (long)((c + 2) * 2 + h) * 64, dummy));
+          a8_gload16_nt(w[par][h][j], a8_sel_ptr(c + 2 < n, wbase[j] + (long)((c + 2) * HL + h) * 64, dummy));
       a8_wait_vm<kWaitX>();                        // x(c+1) must be in LDS before anyone passes the barrier
       __syncthreads();
     };
@@ -215,12 +224,24 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(unsigned char* __restri
   }
 }
 
-template <int MT, int NTW>
-static void launch_a8w8(const GemmParams& p, hipStream_t stream) {
+// 256-element chunks up to 128 rows when K allows it, 128-element chunks otherwise
+static inline int a8w8_ksub(int M, int K) { return (M <= 128 && K % 256 == 0) ? 2 : 1; }
+
+template <int MT, int NTW, int KSUB>
+static void launch_a8w8_k(const GemmParams& p, hipStream_t stream) {
   const int nblocks = (p.ntiles + 4 * NTW - 1) / (4 * NTW);
   dim3 grid(nblocks, p.splitk), block(kA8Threads);
-  constexpr int smem = 2 * MT * 16 * 128;
-  hipLaunchKernelGGL((gemm_a8w8_kernel<MT, NTW>), grid, block, smem, stream, p);
+  constexpr int smem = 2 * MT * 16 * 128 * KSUB;
+  static_assert(smem <= 64 * 1024, "stays within the default dynamic LDS limit");
+  hipLaunchKernelGGL((gemm_a8w8_kernel<MT, NTW, KSUB>), grid, block, smem, stream, p);
+}
+
+template <int MT, int NTW>
+static void launch_a8w8(const GemmParams& p, hipStream_t stream) {
+  if constexpr (MT < 16) {
+    if (a8w8_ksub(p.M, p.K) == 2) { launch_a8w8_k<MT, NTW, 2>(p, stream); return; }
+  }
+  launch_a8w8_k<MT, NTW, 1>(p, stream);
 }
 
 template <int MT>
@@ -263,7 +284,7 @@ extern "C" void dlia_gemm_a8w8(void* out, const void* xq, const float* xscale, c
   if (ntw <= 0 || ntw > 2) ntw = 2;
   if (epi == 4) ntw = 2;
   if (workspace == nullptr) splitk = 1;
-  const int chunks = K / kA8BK;
+  const int chunks = K / (128 * a8w8_ksub(M, K));
   if (splitk > chunks) splitk = chunks;
   p.splitk = splitk;
   if (M <= 64)       launch_a8w8_ntw<4>(p, ntw, stream);

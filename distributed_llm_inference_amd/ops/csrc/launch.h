@@ -12,7 +12,8 @@ extern "C" {
 // (+ pbias). mode: 0 RMSNorm, 1 LayerNorm, 2 only fold the addend into x.
 void dlia_norm(void* out, void* x, const void* delta, const float* partial, int splits, long pM,
                const void* pbias, const void* w, const void* b, const int* row_idx, int rows, int H,
-               long ldx, long ldo, float eps, int mode, hipStream_t stream);
+               long ldx, long ldo, float eps, int mode, float* qscale, hipStream_t stream);
+// qscale != null: `out` receives e4m3 bytes (row stride ldo BYTES) and qscale[r] the row's scale
 
 // ---- embed.hip ------------------------------------------------------------------------
 // out[t,:] = wte[ids[t],:] (+ wpe[pos[t],:])

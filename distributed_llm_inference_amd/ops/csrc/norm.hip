@@ -16,12 +16,14 @@ constexpr int kNormThreads = 256;
 // SRC 0: x as is; 1: x += delta (bf16 [rows,H]); 2: x += sum_s partial[s] (+ pbias) where partial
 // is the fp32 [S][M][H] split-K output of the preceding GEMM — the reduction of those partials
 // costs no launch of its own. In modes 1/2 the updated residual stream is written back into x.
-template <int MODE, int SRC>
+// QOUT: instead of bf16 rows, write the normalised row as OCP e4m3 bytes plus one fp32 scale
+// (max|y| / 448) per row — the input format of the fp8 x fp8 GEMM — saving a quantiser launch.
+template <int MODE, int SRC, bool QOUT>
 __global__ __launch_bounds__(kNormThreads) void norm_kernel(
     bf16* __restrict__ out, bf16* __restrict__ x, const bf16* __restrict__ delta,
     const float* __restrict__ partial, int splits, long pM, const bf16* __restrict__ pbias,
     const bf16* __restrict__ w, const bf16* __restrict__ b, const int* __restrict__ row_idx,
-    int H, long ldx, long ldo, float eps) {
+    int H, long ldx, long ldo, float eps, float* __restrict__ qscale) {
   __shared__ float scratch[16];
   const int orow = blockIdx.x;
   const long irow = row_idx ? row_idx[orow] : orow;
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(kNormThreads) void norm_kernel(
     v = block_sum(v, scratch);
     rstd = rsqrtf(v / H + eps);
   }
-  for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
-    float f[8], g[8], o[8];
+  auto normed = [&](int i, float (&o)[8]) {
+    float f[8], g[8];
     unpack8(ld16(xr + i * 8), f);
     unpack8(ld16(w + i * 8), g);
     if (MODE == 0) {
@@ -108,7 +110,36 @@ __global__ __launch_bounds__(kNormThreads) void norm_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (f[j] - mean) * rstd * g[j] + bb[j];
     }
-    st16(outr + i * 8, pack8(o));
+  };
+  if constexpr (QOUT) {
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
+      float o[8];
+      normed(i, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(o[j]));
+    }
+    amax = block_max(amax, scratch);
+    const float sc = fmaxf(amax, 1e-12f) * (1.f / 448.f);
+    const float inv = 1.f / sc;
+    if (threadIdx.x == 0) qscale[orow] = sc;
+    unsigned char* q = reinterpret_cast<unsigned char*>(out) + (long)orow * ldo;     // ldo in bytes here
+    for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
+      float o[8];
+      normed(i, o);
+      unsigned lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0] * inv, o[1] * inv, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2] * inv, o[3] * inv, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4] * inv, o[5] * inv, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6] * inv, o[7] * inv, hi, true);
+      *reinterpret_cast<u32x2*>(q + i * 8) = u32x2{lo, hi};
+    }
+  } else {
+    for (int i = threadIdx.x; i < nvec; i += kNormThreads) {
+      float o[8];
+      normed(i, o);
+      st16(outr + i * 8, pack8(o));
+    }
   }
 }
 
@@ -120,17 +151,22 @@ using namespace dlia;
 // `partial` (fp32 [splits][pM][H] + optional bias), at most one of them.
 extern "C" void dlia_norm(void* out, void* x, const void* delta, const float* partial, int splits, long pM,
                           const void* pbias, const void* w, const void* b, const int* row_idx, int rows, int H,
-                          long ldx, long ldo, float eps, int mode, hipStream_t stream) {
+                          long ldx, long ldo, float eps, int mode, float* qscale, hipStream_t stream) {
   if (rows <= 0) return;
   dim3 grid(rows), block(kNormThreads);
   bf16* o = (bf16*)out; bf16* xx = (bf16*)x;
   const bf16* d = (const bf16*)delta; const bf16* ww = (const bf16*)w; const bf16* bb = (const bf16*)b;
   const bf16* pb = (const bf16*)pbias;
   const int src = partial ? 2 : (delta ? 1 : 0);
-#define DLIA_NORM(MODE, SRC) hipLaunchKernelGGL((norm_kernel<MODE, SRC>), grid, block, 0, stream, o, xx, d, partial, \
-                                                splits, pM, pb, ww, bb, row_idx, H, ldx, ldo, eps)
+#define DLIA_NORM(MODE, SRC)                                                                                      \
+  do {                                                                                                            \
+    if (qscale) hipLaunchKernelGGL((norm_kernel<MODE, SRC, true>), grid, block, 0, stream, o, xx, d, partial,     \
+                                   splits, pM, pb, ww, bb, row_idx, H, ldx, ldo, eps, qscale);                    \
+    else hipLaunchKernelGGL((norm_kernel<MODE, SRC, false>), grid, block, 0, stream, o, xx, d, partial,           \
+                            splits, pM, pb, ww, bb, row_idx, H, ldx, ldo, eps, qscale);                           \
+  } while (0)
   if (mode == 0)      { if (src == 0) DLIA_NORM(0, 0); else if (src == 1) DLIA_NORM(0, 1); else DLIA_NORM(0, 2); }
   else if (mode == 1) { if (src == 0) DLIA_NORM(1, 0); else if (src == 1) DLIA_NORM(1, 1); else DLIA_NORM(1, 2); }
-  else                { if (src == 1) DLIA_NORM(2, 1); else if (src == 2) DLIA_NORM(2, 2); }
+  else                { qscale = nullptr; if (src == 1) DLIA_NORM(2, 1); else if (src == 2) DLIA_NORM(2, 2); }
 #undef DLIA_NORM
 }

@@ -531,3 +531,27 @@ def test_sampler_distribution(K):
     freq = torch.bincount(out.long(), minlength=V).float() / R
     assert (freq[want == 0] == 0).all()
     assert (freq - want).abs().max() < 0.04
+
+
+@pytest.mark.parametrize("mode", ["rms", "layer"])
+def test_norm_with_quantised_output(K, mode):
+    """norm_q = norm followed by the per-row e4m3 quantiser, in one launch (incl. the partial fold)."""
+    torch.manual_seed(3)
+    M, H, S = 24, 1024, 4
+    x0 = bf(torch.randn(M, H, device=DEV) * 3)
+    g = bf(torch.rand(H, device=DEV) + 0.5)
+    b = bf(torch.randn(H, device=DEV) * 0.1) if mode == "layer" else None
+    part = torch.randn(S, M, H, device=DEV) * 0.3
+    pb = bf(torch.randn(H, device=DEV) * 0.1)
+    m = 0 if mode == "rms" else 1
+    xa, xb = x0.clone(), x0.clone()
+    want = torch.empty_like(x0)
+    K.norm(want, xa, None, part.reshape(-1), S, pb, g, b, None, 1e-5, m)
+    q = torch.zeros(M, 2048, device=DEV, dtype=torch.uint8)[:, :H]
+    sc = torch.zeros(M, device=DEV)
+    K.norm_q(q, sc, xb, None, part.reshape(-1), S, pb, g, b, 1e-5, m)
+    assert torch.equal(xa, xb), "residual stream must be updated identically"
+    deq = packing.dequantize_fp8(q.contiguous(), sc)
+    w = want.float()
+    assert_close(sc, w.abs().amax(1) / 448.0, 2e-2, 1e-6, "row scale")       # bf16 rounding of `want` only
+    assert ((deq - w).abs() <= 0.07 * w.abs() + 0.004 * w.abs().amax(1, keepdim=True)).all()
