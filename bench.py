@@ -53,11 +53,14 @@ def parse():
                     help="fp8: decoder-layer GEMMs on the fp8 MFMA (e4m3 weights + per-row quantised activations); "
                          "fp8w: e4m3 weights only; KV cache and lm_head stay bf16 in both")
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU (torch backend, gloo)")
+    ap.add_argument("--max-seconds", type=float, default=1500.0,
+                    help="abort the whole rank with an error instead of hanging if the run takes longer")
     return ap.parse_args()
 
 
 def baseline_for(model: str):
-    """Reference-path throughput (tok/s) recorded in BASELINE.md for this model, if measured."""
+    """Throughput (tok/s) of the reference's own CPU / JSON-over-HTTP path for this model, as measured
+    by bench/reference_baseline.py and stored in bench/baseline_numbers.json; None if not measured."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench", "baseline_numbers.json")
     try:
         with open(path) as f:
@@ -166,8 +169,24 @@ class _EvHandle:
         return self.ev.query()
 
 
+def _deadline(seconds: float):
+    """A pipeline whose peer died would wait in a receive forever; fail loudly instead."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py: no result after {seconds:.0f} s (rank {os.environ.get('RANK', '0')}), aborting\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     a = parse()
+    timer = _deadline(a.max_seconds)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
@@ -200,8 +219,6 @@ def main():
         elapsed = rt.barrier_times[-1] - rt.barrier_times[-2]
         lat = drv.latencies_ms()
         rt.execute(control(KIND_SHUTDOWN))
-        if rt.links.next_ctrl is not None:
-            pass
     # MAX over ranks
     if world > 1:
         import torch.distributed as dist
@@ -241,6 +258,7 @@ def main():
         except Exception:
             pass
     rt.links.close()
+    timer.cancel()
 
 
 if __name__ == "__main__":

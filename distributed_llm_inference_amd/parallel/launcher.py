@@ -266,9 +266,7 @@ def attach_distributed(cfg: EngineConfig):
     job = f"dlia_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.getppid()}"
     if cfg.pp_size != world:
         cfg = dataclasses.replace(cfg, pp_size=world)
-    if rank == 0:
-        # rank 0 creates the board; others attach with retry inside StatusBoard
-        pass
+    # rank 0 creates the status board; the other ranks attach to it with retries (StatusBoard)
     spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, port, local_rank=local_rank)
     rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path), decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
                       trace_path=cfg.trace_path)
