@@ -259,6 +259,9 @@ def _register_test_models():
     BUILTIN_SPECS["tiny-llama-gpu-test"] = tiny_spec(
         "llama", name="tiny-llama-gpu-test", hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
         intermediate_size=512, vocab_size=320, num_layers=4)
+    BUILTIN_SPECS["tiny-gpt2-gpu-test"] = tiny_spec(
+        "gpt2", name="tiny-gpt2-gpu-test", hidden_size=256, num_heads=4, num_kv_heads=4, head_dim=64,
+        intermediate_size=1024, vocab_size=333, num_layers=4)
 
 
 def tiny_spec(family: str = "llama", **overrides) -> ModelSpec:

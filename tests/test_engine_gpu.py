@@ -140,3 +140,13 @@ def test_checkpoint_directory_on_gpu_matches_transformers(tmp_path):
                 agree += 1
                 ids = torch.cat([ids, torch.tensor([[nxt]])], 1)
     assert agree >= 0.6 * 10 * len(ps), agree
+
+
+@pytest.mark.parametrize("model,dtype", [("tiny-gpt2-gpu-test", "bf16"), (MODEL, "fp8"), (MODEL, "fp8w")])
+def test_other_family_and_fp8_modes_through_the_engine(model, dtype):
+    """GPT-2 family (LayerNorm, biases, GELU, learned positions, tied head) and both fp8 modes run
+    the same serving path: split-invariant greedy tokens, all requests complete."""
+    ps = prompts(7, vocab=300, seed=5)
+    a, snap = run(cfg(model=model, dtype=dtype), ps, greedy(12))
+    b, _ = run(cfg(model=model, dtype=dtype, pp_size=2, num_micro_batches=3), ps, greedy(12))
+    assert a == b and all(len(o) == 12 for o in a) and snap["fatal"] is None
