@@ -255,7 +255,45 @@ __global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmPa
       auto xfrag = [&](int i, int kk) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(xb + (i * 16 + l15) * ROWB + (((kk * 4 + quad) ^ swz(l15)) << 4));
       };
-      if constexpr (XDMA && !W8 && OCC == 1) {
+      if constexpr (XDMA && OCC >= 2 && !W8) {
+        // Two waves per SIMD, 128 accumulator registers: the x fragments are walked in groups of
+        // four m-tiles, double-buffered — the next group's LDS reads are issued before the current
+        // group's MFMAs, across k-step and ring-slot boundaries — and a scheduling barrier per group
+        // keeps hipcc from hoisting more fragments than the register budget holds.
+        constexpr int GPK = MT / 4;                         // groups per k-step
+        constexpr int G = KSTEPS * GPK;
+        u32x4 xg[2][4];
+        u32x4 wf[KPS][NTW];
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) xg[0][i4] = xfrag(i4, 0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int kk = g / GPK, ig = g % GPK;
+          if (g + 1 < G) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) xg[(g + 1) & 1][i4] = xfrag(((g + 1) % GPK) * 4 + i4, (g + 1) / GPK);
+          }
+          if (ig == 0 && kk % KPS == 0) {                   // first use of ring slot kk / KPS
+            if constexpr (refill) wait_vm<kWaitW>();
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) wf[0][j] = w[par * SL + kk / KPS][j];
+          }
+#pragma unroll
+          for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+              acc[ig * 4 + i4][j] = mfma16(wf[kk % KPS][j], xg[g & 1][i4], acc[ig * 4 + i4][j]);
+          if (ig == GPK - 1 && kk % KPS == KPS - 1) {       // last use of the slot: refill it
+            if constexpr (refill) {
+#pragma unroll
+              for (int j = 0; j < NTW; ++j)
+                gload16_nt(w[par * SL + kk / KPS][j],
+                           sel_ptr(!UNIFORM || c + 2 < n, wbase[j] + (long)((c + 2) * SL + kk / KPS) * 64, dummy));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (XDMA && !W8 && OCC == 1) {
         // One wave per SIMD here (128 KiB of LDS per workgroup), so nothing else hides the LDS
         // latency: the x fragments of k-step kk+1 are fetched while the MFMAs of kk run. (Not for
         // fp8 weights: with the widened fragments on top, the register file no longer fits both
