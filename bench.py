@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"],
                     help="fp8: decoder-layer GEMMs on the fp8 MFMA (e4m3 weights + per-row quantised activations); "
                          "fp8w: e4m3 weights only; KV cache and lm_head stay bf16 in both")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "gloo"],
+                    help="activation transport between stages (auto: RCCL on GPUs; gloo = host-staged TCP, which "
+                         "also lets several stages share one GPU for a rehearsal)")
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU (torch backend, gloo)")
     ap.add_argument("--max-seconds", type=float, default=1500.0,
                     help="abort the whole rank with an error instead of hanging if the run takes longer")
@@ -195,7 +198,8 @@ def main():
     cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
                        use_graphs=not a.no_graph, device="cpu" if a.cpu else "auto",
-                       backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype, decode_streams=a.decode_streams)
+                       backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype, decode_streams=a.decode_streams,
+                       transport="gloo" if a.cpu else a.transport)
     rank, world, rt, board, spec, cfg = attach_distributed(cfg)
     if rank != 0:
         stage_main(rt)
@@ -222,7 +226,7 @@ def main():
     # MAX over ranks
     if world > 1:
         import torch.distributed as dist
-        dev = rt.device if rt.on_gpu else "cpu"
+        dev = rt.device if (rt.on_gpu and dist.get_backend() == "nccl") else "cpu"
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -249,7 +253,7 @@ def main():
                        "parallelism": f"pp{world}", "micro_batches": cfg.num_micro_batches,
                        "micro_batch_size": cfg.max_batch, "layer_ranges": plans,
                        "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": cfg.use_graphs, "decode_streams": cfg.decode_streams,
-                       "backend": rt.ex.backend}}), flush=True)
+                       "backend": rt.ex.backend, "transport": cfg.resolved_transport()}}), flush=True)
     if world > 1:
         import torch.distributed as dist
         try:

@@ -158,9 +158,17 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
                         local_rank: Optional[int] = None):
     """Common bring-up of one stage process. Returns (spec, plan, executor, links, board)."""
     dev_kind = cfg.resolved_device()
-    device = f"cuda:{rank if local_rank is None else local_rank}" if dev_kind == "cuda" else "cpu"
     transport = cfg.resolved_transport()
     backend = {"rccl": "nccl", "nccl": "nccl", "gloo": "gloo"}.get(transport, "gloo")
+    device = "cpu"
+    if dev_kind == "cuda":
+        idx = rank if local_rank is None else local_rank
+        ndev = torch.cuda.device_count()
+        if idx >= ndev > 0 and (backend == "gloo" or os.environ.get("DLIA_SHARE_GPU") == "1"):
+            # more stages than GPUs: only the host-staged transport can share a device between ranks
+            # (RCCL refuses two ranks on one GPU); used to rehearse a multi-stage job on a small box
+            idx %= ndev
+        device = f"cuda:{idx}"
     if dev_kind == "cuda":
         torch.cuda.set_device(torch.device(device))
     spec = resolve_spec(cfg)
@@ -171,7 +179,8 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
         if world > 1:
             init_distributed(rank, world, backend, master_port, device if dev_kind == "cuda" else None)
         ex = build_executor(cfg, spec, plan, device=device)
-        links = make_dist_links(rank, world, backend, job) if world > 1 else make_loopback_links(1)[0]
+        links = (make_dist_links(rank, world, backend, job, host_staged=(dev_kind == "cuda" and backend == "gloo"))
+                 if world > 1 else make_loopback_links(1)[0])
     except BaseException as e:
         board.set_state(rank, ST_ERROR, f"{type(e).__name__}: {e}")
         raise
@@ -216,7 +225,8 @@ class SpawnedPipeline:
         try:
             init_distributed(0, world, backend, port, device if dev_kind == "cuda" else None)
             ex = build_executor(cfg, self.spec, self.plan, device=device)
-            self.links = make_dist_links(0, world, backend, self.job)
+            self.links = make_dist_links(0, world, backend, self.job,
+                                         host_staged=(dev_kind == "cuda" and backend == "gloo"))
         except BaseException as e:
             self.board.set_state(0, ST_ERROR, f"{type(e).__name__}: {e}")
             raise

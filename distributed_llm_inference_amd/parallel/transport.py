@@ -83,6 +83,22 @@ class _PolledWorkHandle(Handle):
         return self._flag.is_set()
 
 
+class _StagedRecvHandle(_PolledWorkHandle):
+    """Receive into pinned host memory over gloo, then copy to the GPU buffer on the stream that is
+    current when the consumer waits (the copy is ordered before whatever that stream runs next)."""
+
+    def __init__(self, work, host: torch.Tensor, dev_buf: torch.Tensor):
+        super().__init__(work, keep=host)
+        self.dev_buf = dev_buf
+        self._copied = False
+
+    def wait(self):
+        super().wait()
+        if not self._copied:
+            self.dev_buf.copy_(self.keep, non_blocking=True)
+            self._copied = True
+
+
 class Edge:
     def send(self, t: torch.Tensor) -> Handle:
         raise NotImplementedError
@@ -161,13 +177,19 @@ class _LoopbackRecv(Handle):
 class TorchDistEdge(Edge):
     """One directed hop src_rank -> dst_rank over its own 2-rank process group."""
 
-    def __init__(self, group, src_rank: int, dst_rank: int, my_rank: int):
+    def __init__(self, group, src_rank: int, dst_rank: int, my_rank: int, host_staged: bool = False):
         self.group, self.src, self.dst, self.me = group, src_rank, dst_rank, my_rank
+        self.host_staged = host_staged      # gloo group carrying GPU tensors: bounce through pinned memory
 
     def send(self, t):
         import torch.distributed as dist
         assert self.me == self.src
         t = t.contiguous()
+        if t.is_cuda and self.host_staged:
+            host = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+            host.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()      # the bytes must be on the host before gloo reads them
+            return _PolledWorkHandle(dist.isend(host, self.dst, group=self.group), keep=host)
         cls = _WorkHandle if t.is_cuda else _PolledWorkHandle
         return cls(dist.isend(t, self.dst, group=self.group), keep=t)
 
@@ -175,6 +197,9 @@ class TorchDistEdge(Edge):
         import torch.distributed as dist
         assert self.me == self.dst
         assert buf.is_contiguous()
+        if buf.is_cuda and self.host_staged:
+            host = torch.empty(buf.shape, dtype=buf.dtype, device="cpu", pin_memory=True)
+            return _StagedRecvHandle(dist.irecv(host, self.src, group=self.group), host, buf)
         cls = _WorkHandle if buf.is_cuda else _PolledWorkHandle
         return cls(dist.irecv(buf, self.src, group=self.group))
 
@@ -309,12 +334,15 @@ def _warm_up_edges(edges, rank: int, backend: str):
         torch.cuda.synchronize(dev)
 
 
-def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl: bool = True) -> PipelineLinks:
+def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl: bool = True,
+                    host_staged: bool = False) -> PipelineLinks:
     """Process groups and control rings for rank `rank` of a `world`-stage pipeline.
 
     `torch.distributed` must already be initialised (any backend; sub-groups are created with
     `backend`). new_group() is collective over the default group, so every rank creates every
-    edge's group in the same order, then keeps only its own."""
+    edge's group in the same order, then keeps only its own. `host_staged`: the stages compute on
+    GPUs but the groups are gloo (TCP between nodes without an RCCL fabric, or several stages
+    rehearsing on one GPU) — activations bounce through pinned host memory."""
     import torch.distributed as dist
     links = PipelineLinks(rank, world)
     edges = []
@@ -322,14 +350,14 @@ def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl:
         g = dist.new_group(ranks=[s, s + 1], backend=backend)
         edges.append((g, s, s + 1))
         if rank == s:
-            links.next_data = TorchDistEdge(g, s, s + 1, rank)
+            links.next_data = TorchDistEdge(g, s, s + 1, rank, host_staged)
         elif rank == s + 1:
-            links.prev_data = TorchDistEdge(g, s, s + 1, rank)
+            links.prev_data = TorchDistEdge(g, s, s + 1, rank, host_staged)
     if world > 1:
         g = dist.new_group(ranks=[0, world - 1], backend=backend)     # feedback hop, own communicator
         edges.append((g, world - 1, 0))
         if rank in (0, world - 1):
-            links.fb_data = TorchDistEdge(g, world - 1, 0, rank)
+            links.fb_data = TorchDistEdge(g, world - 1, 0, rank, host_staged)
     _warm_up_edges(edges, rank, backend)
     if use_shm_ctrl:
         # producer creates, consumer attaches (with retry) — no ordering requirement between them

@@ -150,3 +150,22 @@ def test_other_family_and_fp8_modes_through_the_engine(model, dtype):
     a, snap = run(cfg(model=model, dtype=dtype), ps, greedy(12))
     b, _ = run(cfg(model=model, dtype=dtype, pp_size=2, num_micro_batches=3), ps, greedy(12))
     assert a == b and all(len(o) == 12 for o in a) and snap["fatal"] is None
+
+
+def test_two_stage_processes_on_one_gpu_over_host_staged_gloo():
+    """Separate OS processes per stage (the deployment shape), HIP executors in both, activations
+    and token feedback bounced through pinned host memory over gloo — the transport for stages
+    without a shared RCCL fabric, and the only one that lets two ranks share this single GPU.
+    Same greedy tokens as the in-process single-stage engine."""
+    from distributed_llm_inference_amd.parallel.launcher import SpawnedPipeline
+    ps = prompts(6, seed=8)
+    ref, _ = run(cfg(), ps, greedy(12))
+    pipe = SpawnedPipeline(cfg(pp_size=2, partition="even", num_micro_batches=3, transport="gloo"))
+    try:
+        pipe.wait_ready(timeout=240)
+        reqs = [pipe.engine.submit(p, greedy(12)) for p in ps]
+        got = [r.wait(120).output for r in reqs]
+        assert pipe.engine.snapshot()["fatal"] is None
+    finally:
+        pipe.close()
+    assert got == ref
