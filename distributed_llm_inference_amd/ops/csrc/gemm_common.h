@@ -54,15 +54,15 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
 }
 
 
-// Output stage shared by the streaming kernels: acc[i][j][r] = C[m = i*16 + l15][n = (tile0+j)*16 + quad*4 + r].
+// Output stage shared by the streaming kernels: acc[i][j][r] = C[m = m0 + i*16 + l15][n = (tile0+j)*16 + quad*4 + r].
 // Writes fp32 partials (split-K or partial-only), or applies the fused epilogue.
 template <int MT, int NTW>
 __device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc)[MT][NTW], int tile0, int l15,
-                                                int quad, int ks) {
+                                                int quad, int ks, int m0 = 0) {
   if (p.partial_only || p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = i * 16 + l15;
+      const int m = m0 + i * 16 + l15;
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = i * 16 + l15;
+    const int m = m0 + i * 16 + l15;
     if (m >= p.M) continue;
     if (p.act == 1) {
       // tiles (2t, 2t+1) = (gate, up) rows of output columns [16t, 16t+16)
@@ -104,6 +104,7 @@ __device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc
 
 }  // namespace dlia
 extern "C" void dlia_splitk_reduce(const dlia::GemmParams* p, hipStream_t stream);
+extern "C" void dlia_gemm_rows256(const dlia::GemmParams* p, hipStream_t stream);
 extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_split, int* ntw_out, int* splitk_out);
 namespace dlia {
 

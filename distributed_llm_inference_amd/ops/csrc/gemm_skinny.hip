@@ -613,6 +613,12 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
   else if (M <= 32) launch_skinny_ntw<2>(p, ntw, stream);
   else if (M <= 64) launch_skinny_ntw<4>(p, ntw, stream);
   else if (M <= 128) launch_skinny_ntw<8>(p, ntw, stream);
-  else               launch_skinny_ntw<16>(p, ntw, stream);
+  else {
+    // bf16 at 129..256 rows: the all-DMA 8-wave kernel (gemm_rows256.hip); fp8 weights keep the
+    // register-ring variant here, which widens them in registers
+    static const bool old256 = [] { const char* e = getenv("DLIA_GEMM_256_RING"); return e && atoi(e) != 0; }();
+    if (wscale || old256) launch_skinny_ntw<16>(p, ntw, stream);
+    else                  dlia_gemm_rows256(&p, stream);
+  }
   if (splitk > 1 && !p.partial_only) dlia_splitk_reduce(&p, stream);
 }
