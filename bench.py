@@ -9,11 +9,13 @@ random-init weights.
 
 One rank per GPU; rank = pipeline stage; hidden states hop stage to stage over RCCL send/recv,
 sampled token ids hop back from the last stage to stage 0. A "step" is one decode step of EVERY
-in-flight sequence: each of the 3N micro-batches (256 sequences each) goes once through all N
+in-flight sequence: each of the 2N micro-batches (1024 sequences each) goes once through all N
 stages — embedding, every decoder layer against the paged KV cache, final norm, lm_head,
-temperature/top-k/top-p sampling, token feedback. Per-GPU work per step is constant in N (3N
-micro-batches x L/N layers), i.e. weak scaling. A stage rotates its micro-batches over 3 HIP
-streams, so the kernels of up to three micro-batches overlap on each GPU. Prefill of the synthetic prompts and W warm-up
+temperature/top-k/top-p sampling, token feedback. Per-GPU work per step is constant in N (2N
+micro-batches x L/N layers), i.e. weak scaling. A stage rotates its micro-batches over 2 HIP
+streams, so the kernels of two micro-batches overlap on each GPU (measured on one MI355X:
+2 x 1024 rows 57.7k tok/s at 35 ms per token, 3 x 512 53.8k at 28 ms, 3 x 256 42.8k at 18 ms —
+pick the latency point with --batch / --micro-batches / --decode-streams). Prefill of the synthetic prompts and W warm-up
 steps run first; then exactly K steps are timed between barrier + device-synchronize brackets,
 the MAX over ranks is taken, and rank 0 prints one JSON line.
 """
@@ -42,12 +44,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="llama-3-8b")
-    ap.add_argument("--batch", type=int, default=256, help="sequences per micro-batch")
-    ap.add_argument("--micro-batches", type=int, default=0, help="in-flight micro-batches (default 3 x gpus)")
+    ap.add_argument("--batch", type=int, default=1024, help="sequences per micro-batch")
+    ap.add_argument("--micro-batches", type=int, default=0, help="in-flight micro-batches (default 2 x gpus)")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--decode-streams", type=int, default=3,
+    ap.add_argument("--decode-streams", type=int, default=2,
                     help="HIP streams the decode micro-batches of a stage alternate over")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"],
                     help="fp8: decoder-layer GEMMs on the fp8 MFMA (e4m3 weights + per-row quantised activations); "
@@ -193,7 +195,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    nmb = a.micro_batches or 3 * max(1, world)
+    nmb = a.micro_batches or 2 * max(1, world)
     max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
     cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,

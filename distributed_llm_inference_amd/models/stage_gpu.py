@@ -32,7 +32,8 @@ from .spec import ModelSpec
 from .weights import StageWeights
 
 BLOCK = packing.KV_BLOCK
-DECODE_ROWS = 256      # row count up to which GEMMs take the weight-streaming kernel (with split-K partials)
+import os as _os
+DECODE_ROWS = int(_os.environ.get('DLIA_DECODE_ROWS', '256'))      # row count up to which GEMMs take the weight-streaming kernel (with split-K partials)
 
 
 @dataclass

@@ -8,6 +8,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/util/Optional.h>
 
+#include <cstdlib>
 #include "launch.h"
 
 extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits);
@@ -251,8 +252,24 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
     }
   } else {
     DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
-    dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
-                   out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
+    // bf16, more than 256 rows. DLIA_GEMM_LARGE picks the kernel for A/B runs: "big" (256 x 256
+    // tiles), "stream" (256 x 128, the decode kernel walking row blocks), "tile" (128 x 128).
+    static const int which = [] {
+      const char* e = getenv("DLIA_GEMM_LARGE");
+      if (!e) return 0;
+      return e[0] == 'b' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0));
+    }();
+    int k = which;
+    if (k == 0) k = 2;
+    if (k == 1)
+      dlia_gemm_big(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
+                    out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
+    else if (k == 2)
+      dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, nullptr, nullptr, (int)M, (int)N, (int)K,
+                       x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, 1, 2, stream);
+    else
+      dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
+                     out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
   }
 }
 

@@ -68,7 +68,14 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, quad = lane >> 4;
-  const int nblk = blockIdx.x, ks = blockIdx.y;
+  // More than 256 rows: the grid also walks 256-row blocks. Workgroup ids go round-robin over the
+  // 8 XCDs, so the row blocks of one column block get ids that differ by multiples of 8: they run
+  // on the same XCD at about the same time and share each weight byte through its L2.
+  const int mblocks = (p.M + 255) >> 8;
+  const int within = blockIdx.x >> 3;
+  const int nblk = (within / mblocks) * 8 + (blockIdx.x & 7), mrow0 = (within % mblocks) * 256;
+  const int ks = blockIdx.y;
+  if (nblk * 8 >= p.ntiles) return;                         // grid padded to a multiple of 8 column blocks
   const int KT = p.K >> 5;
   const int chunks_total = p.K >> 6;
   const int cper = (chunks_total + p.splitk - 1) / p.splitk;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams 
     for (int q = 0; q < 8; ++q) {
       const int row = 8 * (L * 8 + q) + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
-      xsrc[q] = p.x + (long)(row < p.M ? row : p.M - 1) * p.ldx + slot * 8 + (long)c0 * 64;
+      xsrc[q] = p.x + (long)min(mrow0 + row, p.M - 1) * p.ldx + slot * 8 + (long)c0 * 64;
     }
     const u32x4* wsrc[2];
 #pragma unroll
@@ -182,14 +189,14 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams 
       }
     }
   }
-  write_acc_tiles<8, 2>(p, acc, tile0, l15, quad, ks, mh * 128);
+  write_acc_tiles<8, 2>(p, acc, tile0, l15, quad, ks, mrow0 + mh * 128);
 }
 
 }  // namespace dlia
 
 using namespace dlia;
 
-// Called by dlia_gemm_skinny for bf16 weights and 128 < M <= 256; `p` is fully set up.
+// Called by dlia_gemm_skinny for bf16 weights and M > 128 (any number of 256-row blocks); `p` is fully set up.
 extern "C" void dlia_gemm_rows256(const dlia::GemmParams* p, hipStream_t stream) {
   static const bool once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows256_kernel),
@@ -197,5 +204,6 @@ extern "C" void dlia_gemm_rows256(const dlia::GemmParams* p, hipStream_t stream)
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL(gemm_rows256_kernel, dim3(p->ntiles / 8, p->splitk), dim3(kR2Threads), kR2Lds, stream, *p);
+  const int nblocks8 = (p->ntiles / 8 + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
+  hipLaunchKernelGGL(gemm_rows256_kernel, dim3(nblocks8 * mblocks, p->splitk), dim3(kR2Threads), kR2Lds, stream, *p);
 }

@@ -58,6 +58,9 @@ void dlia_quant_rows(void* q, float* scale, const void* x, int M, int K, long ld
 void dlia_gemm_tile(void* out, const void* x, const void* wp, const void* bias,
                     const void* residual, int M, int N, int K, long ldx, long ldo, long ldr,
                     int epi, int out_f32, hipStream_t stream);
+void dlia_gemm_big(void* out, const void* x, const void* wp, const void* bias,
+                    const void* residual, int M, int N, int K, long ldx, long ldo, long ldr,
+                    int epi, int out_f32, hipStream_t stream);
 
 // ---- attention.hip --------------------------------------------------------------------
 // Causal GQA attention of ragged query chunks against the paged KV cache (prefill chunks and
