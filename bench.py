@@ -44,12 +44,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="llama-3-8b")
-    ap.add_argument("--batch", type=int, default=1024, help="sequences per micro-batch")
-    ap.add_argument("--micro-batches", type=int, default=0, help="in-flight micro-batches (default 2 x gpus)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="sequences per micro-batch (default: 1024 for bf16; 256 for the fp8 modes, whose GEMM\n"
+                         "streams at most 256 rows per pass)")
+    ap.add_argument("--micro-batches", type=int, default=0,
+                    help="in-flight micro-batches (default: 2 x gpus for bf16, 3 x gpus for the fp8 modes)")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--decode-streams", type=int, default=2,
+    ap.add_argument("--decode-streams", type=int, default=0,
                     help="HIP streams the decode micro-batches of a stage alternate over")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"],
                     help="fp8: decoder-layer GEMMs on the fp8 MFMA (e4m3 weights + per-row quantised activations); "
@@ -195,7 +198,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    nmb = a.micro_batches or 2 * max(1, world)
+    # operating point per dtype (measured on one MI355X): bf16 2 x 1024 rows on 2 streams; the fp8
+    # kernels stream at most 256 rows per pass, so larger micro-batches would re-read the weights
+    wide = a.dtype == "bf16"
+    a.batch = a.batch or (8 if a.cpu else (1024 if wide else 256))
+    a.decode_streams = a.decode_streams or (2 if wide else 3)
+    nmb = a.micro_batches or (2 if wide else 3) * max(1, world)
     max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
     cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
