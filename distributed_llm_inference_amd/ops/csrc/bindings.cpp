@@ -8,6 +8,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/util/Optional.h>
 
+#include <atomic>
 #include <cstdlib>
 #include "launch.h"
 
@@ -171,6 +172,22 @@ void rope_kvwrite(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias
                     (int)g.num_blocks, rope_len, use_rope ? 1 : 0, cur_stream());
 }
 
+// Kernel for bf16 GEMMs of more than 256 rows: 0 = default (2), 1 = 256 x 256 tiles, 2 = the streaming
+// kernel walking 256-row blocks, 3 = 128 x 128 tiles. Starts from DLIA_GEMM_LARGE (big / stream /
+// tile); the `large_gemm_kernel` op changes it for A/B runs and tests.
+static std::atomic<int>& large_gemm_choice() {
+  static std::atomic<int> v{[] {
+    const char* e = getenv("DLIA_GEMM_LARGE");
+    if (!e) return 0;
+    return e[0] == 'b' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0));
+  }()};
+  return v;
+}
+int64_t large_gemm_kernel(int64_t which) {
+  DLIA_CHECK(which >= 0 && which <= 3, "large_gemm_kernel: 0 default, 1 big, 2 stream, 3 tile");
+  return large_gemm_choice().exchange((int)which);
+}
+
 // out[M, N_out] = epi(x[M,K] @ W^T); wp = packed weights (uint8 view of the packed image).
 // epi: 0 none, 1 +bias, 2 +residual, 3 +bias+residual, 4 swiglu, 5 +bias -> gelu_tanh.
 // wscale given: wp holds fp8 e4m3 weights (1 byte each) and wscale one fp32 scale per packed row.
@@ -254,12 +271,7 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
     DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
     // bf16, more than 256 rows. DLIA_GEMM_LARGE picks the kernel for A/B runs: "big" (256 x 256
     // tiles), "stream" (256 x 128, the decode kernel walking row blocks), "tile" (128 x 128).
-    static const int which = [] {
-      const char* e = getenv("DLIA_GEMM_LARGE");
-      if (!e) return 0;
-      return e[0] == 'b' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0));
-    }();
-    int k = which;
+    int k = large_gemm_choice().load();
     if (k == 0) k = 2;
     if (k == 1)
       dlia_gemm_big(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
@@ -465,6 +477,7 @@ TORCH_LIBRARY(dlia, m) {
   m.def("quant_rows(Tensor(a!) q, Tensor(b!) scale, Tensor x) -> ()");
   m.def("gemm_config(int M, int N, int K, int epi, bool allow_split) -> int[]");
   m.def("gemm_splitk(int M, int N, int K) -> int");
+  m.def("large_gemm_kernel(int which) -> int");
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
   m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
   m.def("sample(Tensor(a!) out_tokens, Tensor logits, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
@@ -487,6 +500,7 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
 
 TORCH_LIBRARY_IMPL(dlia, CompositeExplicitAutograd, m) {
   m.impl("gemm_splitk", &gemm_splitk);
+  m.impl("large_gemm_kernel", &large_gemm_kernel);
   m.impl("gemm_config", &gemm_config);
   m.impl("attention_ws_floats", &attention_ws_floats);
 }

@@ -331,14 +331,34 @@ def test_gemm_partials_consumed_by_norm_and_rope(K):
         assert_close(o3, ref.rmsnorm(hn[rows.long()], g, 1e-5), 3e-2, 2e-2, "row-gathered norm over partials")
 
 
-@pytest.mark.parametrize("M", [257, 300])
+LARGE_KERNELS = {"stream": 2, "big": 1, "tile": 3}     # see the `large_gemm_kernel` op
+
+
+@pytest.fixture(params=sorted(LARGE_KERNELS))
+def large_kernel(K, request):
+    """Each kernel for more than 256 rows in turn: the streaming kernel walking 256-row blocks (the
+    default), the 256 x 256-tile kernel and the 128 x 128-tile kernel."""
+    prev = K.large_gemm_kernel(LARGE_KERNELS[request.param])
+    yield request.param
+    K.large_gemm_kernel(prev)
+
+
+@pytest.mark.parametrize("M", [257, 300, 520])
 @pytest.mark.parametrize("epi", [0, 3, 4, 5])
-def test_gemm_tile(K, M, epi):
+def test_gemm_large_m(K, large_kernel, M, epi):
+    """Row counts that end inside a 256-row (and 128-row) block: the clamped rows are never stored."""
     _gemm_case(K, M, 1024, 512, epi, 1)
 
 
-def test_gemm_tile_large(K):
+def test_gemm_large_m_llama_shape(K, large_kernel):
     _gemm_case(K, 1024, 6144, 4096, 2, 1)
+
+
+def test_gemm_large_m_column_blocks_not_a_multiple_of_256(K, large_kernel):
+    """N = 1152 packs to 72 n-tiles = 4.5 blocks of 256 columns: the last workgroup of the 256 x 256
+    kernel has only half a block of real weight tiles."""
+    _gemm_case(K, 512, 1152, 1024, 0, 1)
+    _gemm_case(K, 300, 384, 512, 0, 1, out_f32=True)
 
 
 # ------------------------------------------------------------------------------------------
