@@ -28,7 +28,7 @@ def main():
     wp = packing.pack_weight((torch.randn(a.n, a.k, device="cuda") * 0.02).to(torch.bfloat16))
     n_out = a.n // 2 if a.epi == 4 else a.n
     out = torch.empty(a.m, n_out, device="cuda", dtype=torch.bfloat16)
-    ws = torch.empty(16 * a.m * a.n, device="cuda", dtype=torch.float32)
+    ws = torch.empty(16 * a.m * a.n, device="cuda", dtype=torch.float32) if a.m <= 256 else None   # split-K partials: decode regime only
     flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda") if a.flush else None
     evs = []
     for it in range(a.iters + 2):
