@@ -2,7 +2,7 @@
 // on 256 x 256 tiles, K walked in 32-wide steps.
 //
 // With hundreds of rows both operands come out of L2 / Infinity Cache. A 256 x 128 tile
-// (gemm_rows256.hip) moves 48 KiB per 64 K-elements; a 256 x 256 tile moves 64 KiB for twice the
+// (gemm_rows.hip) moves 48 KiB per 64 K-elements; a 256 x 256 tile moves 64 KiB for twice the
 // work, and a compute wave that holds all four weight fragments of a k-step issues 12 LDS fragment
 // reads per 32 MFMAs instead of 20. Its accumulators are half of the CU's register file (8 compute
 // waves x 128 registers), so everything else is kept small enough (163 VGPRs) for three waves per

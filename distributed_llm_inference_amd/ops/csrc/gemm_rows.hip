@@ -1,26 +1,33 @@
-// Weight-streaming bf16 GEMM for 129..256 activation rows: out[M,N] = epi(x[M,K] @ W[N,K]^T).
+// Weight-streaming bf16 GEMM with both operands moved by DMA: out[M,N] = epi(x[M,K] @ W[N,K]^T)
+// for M > 128 — decode batches of 129..256 rows (one row block, split-K partials available) and,
+// above that, prefill chunks / large decode batches as a grid of 256-row blocks.
 //
-// At this row count the launch is bound by neither HBM nor the matrix cores alone but by keeping
-// two streams in flight per CU at once: every workgroup re-stages all of x from L2 (470 MB for the
-// Llama-3-8B gate/up shape) while it streams its own weight columns from HBM (235 MB). Measured on
-// MI355X with the compute removed, x alone moves at the L2 ceiling (19 TB/s), the weights alone at
-// the HBM ceiling (5.5 TB/s), both together in ~55 us; the kernel's job is to add as little as
-// possible to that. It therefore
+// A workgroup owns 256 x 128 outputs and walks K in 64-wide chunks. Every workgroup re-stages its
+// x rows from L2 while it streams its own weight columns from HBM; measured on MI355X with the
+// compute removed (256 rows, Llama-3-8B gate/up shape), x alone moves at the L2 ceiling
+// (19 TB/s), the weights alone at the HBM ceiling (5.5 TB/s), both together in ~55 us: the
+// kernel's job is to add as little as possible to that. It therefore
 //  * moves BOTH operands global -> LDS by DMA (no register ring): three 32 KiB stages of x
-//    (prefetched two chunks ahead) and a four-deep ring of 16 KiB weight slots (three chunks =
-//    48 KiB per CU ahead) — all 160 KiB of LDS — with one hand-counted vmcnt + one barrier per
-//    64-wide K chunk; the weight DMA is non-temporal so the stream cannot evict x from L2;
-//  * splits the workgroup into 8 compute waves (two per SIMD) on a 256 x 128 tile — wave (mh, nq)
-//    owns rows [128 mh, +128) x n-tiles [2 nq, +2), 64 accumulator registers, the two row halves
-//    sharing each weight fragment through the LDS ring — and 4 loader waves that do nothing but
-//    issue the DMA: with the loads issued by the compute waves themselves the same kernel took
-//    72 us instead of 59 (a wave blocked in a full memory queue issues no MFMAs).
+//    (prefetched two chunks ahead) and a ring of three 16 KiB weight slots — 144 KiB of LDS, which
+//    leaves room for a small kernel of another stream on the CU — with one hand-counted vmcnt +
+//    one barrier per chunk; the weight DMA is non-temporal so the stream cannot evict x from L2;
+//  * splits the workgroup into 8 compute waves (two per SIMD) — wave (mh, nq) owns rows
+//    [128 mh, +128) x n-tiles [2 nq, +2), 64 accumulator registers, the two row halves sharing
+//    each weight fragment through the LDS ring — and 4 loader waves that do nothing but issue the
+//    DMA: with the loads issued by the compute waves themselves the same kernel took 72 us
+//    instead of 59 (a wave blocked in a full memory queue issues no MFMAs).
+// The kernel is written for any ROWS in {32, 64, 128, 256} per workgroup (fewer rows shrink the x
+// stages and deepen the weight ring to 5-7 chunks), and those variants pass the numerics tests,
+// but only ROWS = 256 is launched: measured at 1 / 64 / 128 rows a decode step takes 3.73 / 4.30 /
+// 5.41 ms with them against 3.58 / 4.31 / 5.41 ms with the register-ring kernels of
+// gemm_skinny.hip, which already stream the large shapes at the HBM ceiling there (gate/up
+// 5.3 TB/s at 64 rows) — a deeper ring has nothing left to hide.
 // Weights are the packed-B image (ops/packing.py): a (n-tile, k-step) block is 64 lanes x 16 B in
 // fragment order, so its LDS image is lane-linear and conflict-free; x rows are 128 B with the
 // 16-B slot XOR-swizzled by (row >> 1) & 7, applied to the DMA source column and to the read.
 //
 // Replaces the nn.Linear calls inside HF LlamaDecoderLayer that the reference runs on CPU in
-// fp32 (Worker1.py:128-137) and the lm_head (orchestration.py:141) for large decode batches.
+// fp32 (Worker1.py:128-137) and the lm_head (orchestration.py:141).
 #include "common.h"
 #include "gemm_common.h"
 #include "launch.h"
@@ -29,10 +36,18 @@ namespace dlia {
 
 constexpr int kR2Threads = 768;                   // 8 compute waves + 4 loader waves
 constexpr int kR2XS = 3;                          // x stages
-constexpr int kR2WD = 3;                          // weight ring depth (chunks)
-constexpr int kR2XStage = 256 * 64 * 2;           // 32 KiB
 constexpr int kR2WSlot = 128 * 64 * 2;            // 16 KiB = 8 n-tiles x 2 k-steps x 1 KiB
-constexpr int kR2Lds = kR2XS * kR2XStage + kR2WD * kR2WSlot;
+
+template <int ROWS>
+struct RowsCfg {
+  static constexpr int MTW = ROWS / 32;           // m-tiles per compute wave (rows / 2 halves / 16)
+  static constexpr int XP = ROWS / 32;            // x pieces (8 rows x 128 B) per loader and chunk
+  static constexpr int XStage = ROWS * 128;       // bytes of one x stage
+  static constexpr int WD = ROWS == 256 ? 3 : (ROWS == 128 ? 6 : (ROWS == 64 ? 7 : 8));   // weight ring slots
+  static constexpr int LW = WD - 1;               // chunks the weight stream runs ahead
+  static constexpr int Lds = kR2XS * XStage + WD * kR2WSlot;
+  static_assert(2 * XP + 4 * LW <= 63, "vmcnt is a 6-bit counter");
+};
 
 // 16 B per lane, global -> LDS: lane l lands at lds_addr + 16 l. M0 carries the wave-uniform LDS
 // address and is restored, since the compiler does not expect inline asm to change it.
@@ -63,7 +78,10 @@ __device__ __forceinline__ const void* r2_sel(bool c, const void* a, const void*
 // saturated blocks in the issue until the queue has room, and a blocked wave issues no MFMAs —
 // with loader waves the matrix cores never see that back-pressure. Four loaders, because one
 // wave can have at most 63 loads in flight (vmcnt is a 6-bit counter) and the CU needs ~112.
-__global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams p) {
+template <int ROWS>
+__global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) {
+  using C = RowsCfg<ROWS>;
+  constexpr int XP = C::XP, MTW = C::MTW, LW = C::LW, WD = C::WD;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,7 +89,7 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams 
   // More than 256 rows: the grid also walks 256-row blocks. Workgroup ids go round-robin over the
   // 8 XCDs, so the row blocks of one column block get ids that differ by multiples of 8: they run
   // on the same XCD at about the same time and share each weight byte through its L2.
-  const int mblocks = (p.M + 255) >> 8;
+  const int mblocks = ROWS == 256 ? (p.M + 255) >> 8 : 1;
   const int within = blockIdx.x >> 3;
   const int nblk = (within / mblocks) * 8 + (blockIdx.x & 7), mrow0 = (within % mblocks) * 256;
   const int ks = blockIdx.y;
@@ -84,16 +102,16 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams 
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
 
   if (wave >= 8) {
-    // ---------------- loader L: x rows [64 L, +64) and the weight blocks of n-quad L ----------------
+    // ---------------- loader L: x rows [ROWS/4 L, +ROWS/4) and the weight blocks of n-quad L ----------------
     if (n <= 0) return;
     const int L = wave - 8;
     const void* const dummy = p.x;                          // 16 valid, L2-hot bytes
     // one DMA instruction fills 1 KiB: 8 x rows of 128 B (rows past M re-read the last row, never
     // stored to the output), or one (n-tile, k-step) weight block
-    const bf16* xsrc[8];
+    const bf16* xsrc[XP];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int row = 8 * (L * 8 + q) + (lane >> 3);
+    for (int q = 0; q < XP; ++q) {
+      const int row = 8 * (L * XP + q) + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
       xsrc[q] = p.x + (long)min(mrow0 + row, p.M - 1) * p.ldx + slot * 8 + (long)c0 * 64;
     }
@@ -102,8 +120,8 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams 
     for (int j = 0; j < 2; ++j) wsrc[j] = p.wp + ((long)((nblk * 4 + L) * 2 + j) * KT + (long)c0 * 2) * 64 + lane;
     auto xdma = [&](int stage, int c) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        r2_dma16(xsrc[q] + (long)c * 64, lds0 + stage * kR2XStage + (L * 8 + q) * 1024);
+      for (int q = 0; q < XP; ++q)
+        r2_dma16(xsrc[q] + (long)c * 64, lds0 + stage * C::XStage + (L * XP + q) * 1024);
     };
     auto wdma = [&](int slot, int c) {
 #pragma unroll
@@ -111,99 +129,104 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows256_kernel(GemmParams 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
           r2_dma16_nt(r2_sel(c < n, wsrc[j] + (long)(c * 2 + kk) * 64, dummy),
-                      lds0 + kR2XS * kR2XStage + slot * kR2WSlot + ((L * 2 + j) * 2 + kk) * 1024);
+                      lds0 + kR2XS * C::XStage + slot * kR2WSlot + ((L * 2 + j) * 2 + kk) * 1024);
     };
-    // kR2WD == 4 — issue order: W(0) | X(0) W(1) | X(1) W(2) | then chunk c issues X(c+2) W(c+3).
-    // At the top of chunk c the loads younger than X(c) are W(c+1) X(c+1) W(c+2) = 4 + 8 + 4, so
-    // vmcnt(16) means this loader's pieces of X(c) and of the older W(c) have landed.
-    // kR2WD == 3 — X(0) W(0) | X(1) W(1) | then X(c+2) W(c+2); younger than W(c) are X(c+1)
-    // W(c+1) = 8 + 4 -> vmcnt(12).
+    // Per loader a chunk is XP x pieces and 4 weight pieces. Steady state: chunk c issues X(c+2)
+    // then W(c+LW); the prologue issues W(0) .. W(LW-3) and then plays iterations -2 and -1.
+    //  * LW >= 3: the loads younger than X(c) at the top of chunk c are W(c-2+LW) X(c+1) W(c-1+LW),
+    //    so vmcnt(XP + 8) means this loader's pieces of X(c) and of the older W(c) have landed.
+    //  * LW == 2: W(c) is issued right after X(c); younger than it are X(c+1) W(c+1) -> vmcnt(XP + 4).
     // The barrier extends "landed" to all loaders, and tells them every compute wave is done
     // reading chunk c-1, whose x stage and weight slot the new loads overwrite. Loads past the end
     // of the split re-read the last x chunk / a dummy line into buffers nobody reads again, so
     // the count holds to the last chunk.
-    constexpr int LW = kR2WD - 1;                           // chunks the weight stream runs ahead
-    if constexpr (LW == 3) {
-      wdma(0, 0);
-      xdma(0, 0); wdma(1, 1);
-      xdma(1, min(1, n - 1)); wdma(2, 2);
-    } else {
-      xdma(0, 0); wdma(0, 0);
-      xdma(1, min(1, n - 1)); wdma(1, 1);
-    }
+#pragma unroll
+    for (int i = 0; i + 2 < LW; ++i) wdma(i, i);
+    xdma(0, 0); wdma(LW - 2, LW - 2);
+    xdma(1, min(1, n - 1)); wdma(LW - 1, LW - 1);
     int xs = 0, wsl = 0;
     for (int c = 0; c < n; ++c) {
-      r2_wait_vm<LW == 3 ? 16 : 12>();
+      r2_wait_vm<LW >= 3 ? XP + 8 : XP + 4>();
       __builtin_amdgcn_s_barrier();
       xdma(xs >= 1 ? xs - 1 : 2, min(c + 2, n - 1));          // stage (c + 2) % 3
-      wdma(wsl >= 1 ? wsl - 1 : kR2WD - 1, c + LW);           // slot (c + LW) % kR2WD
+      wdma(wsl >= 1 ? wsl - 1 : WD - 1, c + LW);              // slot (c + LW) % WD
       xs = xs == 2 ? 0 : xs + 1;
-      wsl = wsl == kR2WD - 1 ? 0 : wsl + 1;
+      wsl = wsl == WD - 1 ? 0 : wsl + 1;
     }
     r2_wait_vm<0>();                                        // no DMA may land after the workgroup is gone
     return;
   }
 
-  // ---------------- compute wave (mh, nq): rows [128 mh, +128) x n-tiles [2 nq, +2) ----------------
+  // ---------------- compute wave (mh, nq): rows [ROWS/2 mh, +ROWS/2) x n-tiles [2 nq, +2) ----------------
   const int mh = wave >> 2, nq = wave & 3;
   const int tile0 = (nblk * 4 + nq) * 2;                    // (ntiles is a multiple of 8 by packing)
-  f32x4 acc[8][2];
+  f32x4 acc[MTW][2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
+    // the x fragments are walked in groups of GS m-tiles, the next group's LDS reads in flight
+    // while the MFMAs of the current one issue, across the two k-steps of the chunk
+    constexpr int GS = MTW < 4 ? MTW : 4, GPK = MTW / GS, G = 2 * GPK;
     int xs = 0, wsl = 0;
-    const int xoff = (mh * 128 + l15) * 128;
+    const int xoff = (mh * (ROWS / 2) + l15) * 128;
     const int sw = (l15 >> 1) & 7;
     for (int c = 0; c < n; ++c) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      const char* xb = smem + xs * kR2XStage + xoff;
-      const char* wb = smem + kR2XS * kR2XStage + wsl * kR2WSlot + nq * 4096 + lane * 16;
+      const char* xb = smem + xs * C::XStage + xoff;
+      const char* wb = smem + kR2XS * C::XStage + wsl * kR2WSlot + nq * 4096 + lane * 16;
       xs = xs == 2 ? 0 : xs + 1;
-      wsl = wsl == kR2WD - 1 ? 0 : wsl + 1;
+      wsl = wsl == WD - 1 ? 0 : wsl + 1;
       auto xfrag = [&](int i, int kk) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(xb + i * 2048 + (((kk * 4 + quad) ^ sw) << 4));
       };
-      u32x4 wf[2][2], xg[2][4];
+      u32x4 wf[2][2], xg[2][GS];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < 2; ++j) wf[kk][j] = *reinterpret_cast<const u32x4*>(wb + (j * 2 + kk) * 1024);
 #pragma unroll
-      for (int i4 = 0; i4 < 4; ++i4) xg[0][i4] = xfrag(i4, 0);
+      for (int i4 = 0; i4 < GS; ++i4) xg[0][i4] = xfrag(i4, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {                           // (k-step, half of the m-tiles)
-        const int kk = g >> 1, ig = g & 1;
-        if (g + 1 < 4) {
+      for (int g = 0; g < G; ++g) {                           // (k-step, group of m-tiles)
+        const int kk = g / GPK, ig = g % GPK;
+        if (g + 1 < G) {
 #pragma unroll
-          for (int i4 = 0; i4 < 4; ++i4) xg[(g + 1) & 1][i4] = xfrag(((g + 1) & 1) * 4 + i4, (g + 1) >> 1);
+          for (int i4 = 0; i4 < GS; ++i4) xg[(g + 1) & 1][i4] = xfrag(((g + 1) % GPK) * GS + i4, (g + 1) / GPK);
         }
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4)
+        for (int i4 = 0; i4 < GS; ++i4)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[ig * 4 + i4][j] = mfma16(wf[kk][j], xg[g & 1][i4], acc[ig * 4 + i4][j]);
+            acc[ig * GS + i4][j] = mfma16(wf[kk][j], xg[g & 1][i4], acc[ig * GS + i4][j]);
         __builtin_amdgcn_sched_barrier(0);                    // keep the next group's reads ahead of these MFMAs
       }
     }
   }
-  write_acc_tiles<8, 2>(p, acc, tile0, l15, quad, ks, mrow0 + mh * 128);
+  write_acc_tiles<MTW, 2>(p, acc, tile0, l15, quad, ks, mrow0 + mh * (ROWS / 2));
+}
+
+template <int ROWS>
+static void launch_rows(const GemmParams& p, hipStream_t stream) {
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<ROWS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, RowsCfg<ROWS>::Lds);
+    return true;
+  }();
+  (void)once;
+  const int nblocks8 = (p.ntiles / 8 + 7) / 8 * 8, mblocks = ROWS == 256 ? (p.M + 255) / 256 : 1;
+  hipLaunchKernelGGL(gemm_rows_kernel<ROWS>, dim3(nblocks8 * mblocks, p.splitk), dim3(kR2Threads), RowsCfg<ROWS>::Lds,
+                     stream, p);
 }
 
 }  // namespace dlia
 
 using namespace dlia;
 
-// Called by dlia_gemm_skinny for bf16 weights and M > 128 (any number of 256-row blocks); `p` is fully set up.
-extern "C" void dlia_gemm_rows256(const dlia::GemmParams* p, hipStream_t stream) {
-  static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows256_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kR2Lds);
-    return true;
-  }();
-  (void)once;
-  const int nblocks8 = (p->ntiles / 8 + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
-  hipLaunchKernelGGL(gemm_rows256_kernel, dim3(nblocks8 * mblocks, p->splitk), dim3(kR2Threads), kR2Lds, stream, *p);
+// Called by dlia_gemm_skinny for bf16 weights and M > 128; `p` is fully set up (split-K only up to
+// 256 rows).
+extern "C" void dlia_gemm_rows(const dlia::GemmParams* p, hipStream_t stream) {
+  launch_rows<256>(*p, stream);
 }

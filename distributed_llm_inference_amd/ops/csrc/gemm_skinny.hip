@@ -609,16 +609,17 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
   const int chunks = K / kSkinnyBK;
   if (splitk > chunks) splitk = chunks;
   p.splitk = splitk;
-  if (M <= 16)      launch_skinny_ntw<1>(p, ntw, stream);
-  else if (M <= 32) launch_skinny_ntw<2>(p, ntw, stream);
-  else if (M <= 64) launch_skinny_ntw<4>(p, ntw, stream);
+  // bf16 above 128 rows: the all-DMA kernel with loader waves (gemm_rows.hip). Up to 128 rows the
+  // register-ring variants here already stream at the HBM ceiling; fp8 weights use them at every
+  // row count (they widen the weights in registers). DLIA_GEMM_RING=1 selects them for bf16 at
+  // 129..256 rows as well (A/B runs).
+  static const bool ring = [] { const char* e = getenv("DLIA_GEMM_RING"); return e && atoi(e) != 0; }();
+  if (!wscale && M > 128 && !(ring && M <= 256)) {
+    dlia_gemm_rows(&p, stream);
+  } else if (M <= 16)  launch_skinny_ntw<1>(p, ntw, stream);
+  else if (M <= 32)  launch_skinny_ntw<2>(p, ntw, stream);
+  else if (M <= 64)  launch_skinny_ntw<4>(p, ntw, stream);
   else if (M <= 128) launch_skinny_ntw<8>(p, ntw, stream);
-  else {
-    // bf16 at 129..256 rows: the all-DMA 8-wave kernel (gemm_rows256.hip); fp8 weights keep the
-    // register-ring variant here, which widens them in registers
-    static const bool old256 = [] { const char* e = getenv("DLIA_GEMM_256_RING"); return e && atoi(e) != 0; }();
-    if (wscale || old256) launch_skinny_ntw<16>(p, ntw, stream);
-    else                  dlia_gemm_rows256(&p, stream);
-  }
+  else               launch_skinny_ntw<16>(p, ntw, stream);
   if (splitk > 1 && !p.partial_only) dlia_splitk_reduce(&p, stream);
 }
