@@ -45,10 +45,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--batch", type=int, default=0,
-                    help="sequences per micro-batch (default: 1024 for bf16; 256 for the fp8 modes, whose GEMM\n"
+                    help="sequences per micro-batch (default: 1024 for bf16 and fp8; 256 for fp8w, whose GEMM\n"
                          "streams at most 256 rows per pass)")
     ap.add_argument("--micro-batches", type=int, default=0,
-                    help="in-flight micro-batches (default: 2 x gpus for bf16, 3 x gpus for the fp8 modes)")
+                    help="in-flight micro-batches (default: 2 x gpus for bf16 and fp8, 3 x gpus for fp8w)")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")
     ap.add_argument("--no-graph", action="store_true")
@@ -198,9 +198,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    # operating point per dtype (measured on one MI355X): bf16 2 x 1024 rows on 2 streams; the fp8
-    # kernels stream at most 256 rows per pass, so larger micro-batches would re-read the weights
-    wide = a.dtype == "bf16"
+    # operating point per dtype (measured on one MI355X): bf16 and fp8 2 x 1024 rows on 2 streams;
+    # the fp8-weights-only GEMM streams at most 256 rows per pass, so larger micro-batches would
+    # re-read its weights
+    wide = a.dtype in ("bf16", "fp8")
     a.batch = a.batch or (8 if a.cpu else (1024 if wide else 256))
     a.decode_streams = a.decode_streams or (2 if wide else 3)
     nmb = a.micro_batches or (2 if wide else 3) * max(1, world)

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--m", type=int, nargs="+", default=[512, 2048, 8192])
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--a8w8", action="store_true", help="the fp8 x fp8 kernel (e4m3 operands, MX MFMA) instead of bf16")
     a = ap.parse_args()
     K = ops.load()
     s = ModelSpec.from_pretrained(a.model)
@@ -29,12 +30,23 @@ def main():
             n_out = N // 2 if epi == 4 else N
             out = torch.empty(M, n_out, device="cuda", dtype=torch.bfloat16)
             res = torch.randn(M, n_out, device="cuda").to(torch.bfloat16) if epi == 2 else None
+            if a.a8w8:
+                wq, wsc = packing.pack_weight_a8w8(torch.randn(N, Kd, device="cuda") * 0.02)
+                xq = torch.zeros(M, Kd, device="cuda", dtype=torch.uint8)
+                xs = torch.zeros(M, device="cuda")
+                K.quant_rows(xq, xs, x)
+
+            def run():
+                if a.a8w8:
+                    K.gemm_a8w8(out, xq, xs, wq, wsc, None, res, None, N, epi, 1, 0)
+                else:
+                    K.gemm(out, x, wp, None, res, None, N, epi, 1, 0)
             for _ in range(2):
-                K.gemm(out, x, wp, None, res, None, N, epi, 1, 0)
+                run()
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ev[0].record()
             for _ in range(a.iters):
-                K.gemm(out, x, wp, None, res, None, N, epi, 1, 0)
+                run()
             ev[1].record()
             torch.cuda.synchronize()
             t = ev[0].elapsed_time(ev[1]) / a.iters * 1e-3

@@ -368,14 +368,9 @@ void gemm_a8w8(Tensor out, const Tensor& xq, const Tensor& xscale, const Tensor&
                    ws, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, (int)ntw, stream);
   } else {
     DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
-    const int64_t osz = out.element_size();
-    for (int64_t m0 = 0; m0 < M; m0 += 256) {
-      const int64_t mm = std::min<int64_t>(256, M - m0);
-      const char* rps = rp ? (const char*)rp + m0 * ldr * 2 : nullptr;
-      dlia_gemm_a8w8((char*)out.data_ptr() + m0 * out.stride(0) * osz, (const char*)xq.data_ptr() + m0 * xq.stride(0),
-                     xscale.data_ptr<float>() + m0, wp.data_ptr(), wscale.data_ptr<float>(), bp, rps, nullptr, (int)mm,
-                     (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, 1, 2, stream);
-    }
+    // more than 256 rows: one launch, the kernel walks 256-row blocks
+    dlia_gemm_a8w8(out.data_ptr(), xq.data_ptr(), xscale.data_ptr<float>(), wp.data_ptr(), wscale.data_ptr<float>(), bp, rp,
+                   nullptr, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, 1, 2, stream);
   }
 }
 

@@ -262,7 +262,7 @@ extern "C" void dlia_quant_rows(void* q, float* scale, const void* x, int M, int
 }
 
 // Same contract as dlia_gemm_skinny, with xq = e4m3 bytes [M, K] (row stride ldx bytes), xscale[M],
-// wp from pack_weight_a8w8 and wscale per packed row. M <= 256.
+// wp from pack_weight_a8w8 and wscale per packed row. Split-K (workspace) only up to 256 rows.
 extern "C" void dlia_gemm_a8w8(void* out, const void* xq, const float* xscale, const void* wp, const float* wscale,
                                const void* bias, const void* residual, float* workspace, int M, int N, int K,
                                long ldx, long ldo, long ldr, int epi, int out_f32, int splitk, int ntw,
@@ -287,7 +287,11 @@ extern "C" void dlia_gemm_a8w8(void* out, const void* xq, const float* xscale, c
   const int chunks = K / (128 * a8w8_ksub(M, K));
   if (splitk > chunks) splitk = chunks;
   p.splitk = splitk;
-  if (M <= 64)       launch_a8w8_ntw<4>(p, ntw, stream);
+  // above 128 rows: the all-DMA kernel with loader waves (gemm_rows.hip, fp8 variant), which also
+  // walks 256-row blocks for M > 256; DLIA_GEMM_RING=1 keeps the register-ring variant at 129..256
+  static const bool ring = [] { const char* e = getenv("DLIA_GEMM_RING"); return e && atoi(e) != 0; }();
+  if (M > 256 || (M > 128 && !ring)) dlia_gemm_rows_f8(&p, stream);
+  else if (M <= 64)  launch_a8w8_ntw<4>(p, ntw, stream);
   else if (M <= 128) launch_a8w8_ntw<8>(p, ntw, stream);
   else               launch_a8w8_ntw<16>(p, ntw, stream);
   if (splitk > 1 && !p.partial_only) dlia_splitk_reduce(&p, stream);

@@ -34,6 +34,8 @@
 
 namespace dlia {
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
 constexpr int kR2Threads = 768;                   // 8 compute waves + 4 loader waves
 constexpr int kR2XS = 3;                          // x stages
 constexpr int kR2WSlot = 128 * 64 * 2;            // 16 KiB = 8 n-tiles x 2 k-steps x 1 KiB
@@ -78,7 +80,13 @@ __device__ __forceinline__ const void* r2_sel(bool c, const void* a, const void*
 // saturated blocks in the issue until the queue has room, and a blocked wave issues no MFMAs —
 // with loader waves the matrix cores never see that back-pressure. Four loaders, because one
 // wave can have at most 63 loads in flight (vmcnt is a 6-bit counter) and the CU needs ~112.
-template <int ROWS>
+// F8: both operands are OCP e4m3 bytes (x rows of p.ldx BYTES with per-row scales p.xscale, W from
+// pack_weight_a8w8 with per-column scales p.wscale). A 128-byte x row then holds 128 K-elements and
+// the two 1 KiB weight blocks of a (n-tile, chunk) are the two halves of one 32-byte-per-lane
+// fragment, so every byte count, LDS address and wait count below is the same as for bf16; only the
+// chunk covers twice the K and is consumed by v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales,
+// lane l = (r, q) holds k = 32 q .. 32 q + 31 of row r: 16-B slots 2q and 2q + 1 of its x row).
+template <int ROWS, bool F8>
 __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) {
   using C = RowsCfg<ROWS>;
   constexpr int XP = C::XP, MTW = C::MTW, LW = C::LW, WD = C::WD;
@@ -94,8 +102,8 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
   const int nblk = (within / mblocks) * 8 + (blockIdx.x & 7), mrow0 = (within % mblocks) * 256;
   const int ks = blockIdx.y;
   if (nblk * 8 >= p.ntiles) return;                         // grid padded to a multiple of 8 column blocks
-  const int KT = p.K >> 5;
-  const int chunks_total = p.K >> 6;
+  const int chunks_total = p.K >> (F8 ? 7 : 6);             // chunk = 128 bytes of an x row
+  const int KT = chunks_total * 2;                          // 1 KiB weight blocks per n-tile
   const int cper = (chunks_total + p.splitk - 1) / p.splitk;
   const int c0 = ks * cper;
   const int n = min(chunks_total, c0 + cper) - c0;          // chunks of this split
@@ -108,12 +116,13 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     const void* const dummy = p.x;                          // 16 valid, L2-hot bytes
     // one DMA instruction fills 1 KiB: 8 x rows of 128 B (rows past M re-read the last row, never
     // stored to the output), or one (n-tile, k-step) weight block
-    const bf16* xsrc[XP];
+    const char* xsrc[XP];
+    const long ldxb = F8 ? p.ldx : p.ldx * 2;               // row stride in bytes
 #pragma unroll
     for (int q = 0; q < XP; ++q) {
       const int row = 8 * (L * XP + q) + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
-      xsrc[q] = p.x + (long)min(mrow0 + row, p.M - 1) * p.ldx + slot * 8 + (long)c0 * 64;
+      xsrc[q] = reinterpret_cast<const char*>(p.x) + (long)min(mrow0 + row, p.M - 1) * ldxb + slot * 16 + (long)c0 * 128;
     }
     const u32x4* wsrc[2];
 #pragma unroll
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     auto xdma = [&](int stage, int c) {
 #pragma unroll
       for (int q = 0; q < XP; ++q)
-        r2_dma16(xsrc[q] + (long)c * 64, lds0 + stage * C::XStage + (L * XP + q) * 1024);
+        r2_dma16(xsrc[q] + (long)c * 128, lds0 + stage * C::XStage + (L * XP + q) * 1024);
     };
     auto wdma = [&](int slot, int c) {
 #pragma unroll
@@ -182,6 +191,37 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
       auto xfrag = [&](int i, int kk) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(xb + i * 2048 + (((kk * 4 + quad) ^ sw) << 4));
       };
+      if constexpr (F8) {
+        // one MX MFMA per (m-tile, n-tile) and chunk; fragments are 32 bytes per lane
+        i32x8 wf8[2], xq[2][GS];
+        auto xfrag8 = [&](int i) -> i32x8 {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(xb + i * 2048 + (((2 * quad) ^ sw) << 4));
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(xb + i * 2048 + (((2 * quad + 1) ^ sw) << 4));
+          return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        };
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32x4 lo = *reinterpret_cast<const u32x4*>(wb + (j * 2) * 1024);
+          const u32x4 hi = *reinterpret_cast<const u32x4*>(wb + (j * 2 + 1) * 1024);
+          wf8[j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int i4 = 0; i4 < GS; ++i4) xq[0][i4] = xfrag8(i4);
+#pragma unroll
+        for (int g = 0; g < GPK; ++g) {
+          if (g + 1 < GPK) {
+#pragma unroll
+            for (int i4 = 0; i4 < GS; ++i4) xq[(g + 1) & 1][i4] = xfrag8((g + 1) * GS + i4);
+          }
+#pragma unroll
+          for (int i4 = 0; i4 < GS; ++i4)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[g * GS + i4][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                  wf8[j], xq[g & 1][i4], acc[g * GS + i4][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       u32x4 wf[2][2], xg[2][GS];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -203,21 +243,38 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
             acc[ig * GS + i4][j] = mfma16(wf[kk][j], xg[g & 1][i4], acc[ig * GS + i4][j]);
         __builtin_amdgcn_sched_barrier(0);                    // keep the next group's reads ahead of these MFMAs
       }
+      }
+    }
+  }
+  if constexpr (F8) {
+    // dequantise: per output column (weight row) and per row (token)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + (tile0 + j) * 16 + quad * 4);
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) acc[i][j] *= sc;
+    }
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int m = mrow0 + mh * (ROWS / 2) + i * 16 + l15;
+      const float xs = p.xscale[m < p.M ? m : p.M - 1];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] *= xs;
     }
   }
   write_acc_tiles<MTW, 2>(p, acc, tile0, l15, quad, ks, mrow0 + mh * (ROWS / 2));
 }
 
-template <int ROWS>
+template <int ROWS, bool F8>
 static void launch_rows(const GemmParams& p, hipStream_t stream) {
   static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<ROWS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<ROWS, F8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, RowsCfg<ROWS>::Lds);
     return true;
   }();
   (void)once;
   const int nblocks8 = (p.ntiles / 8 + 7) / 8 * 8, mblocks = ROWS == 256 ? (p.M + 255) / 256 : 1;
-  hipLaunchKernelGGL(gemm_rows_kernel<ROWS>, dim3(nblocks8 * mblocks, p.splitk), dim3(kR2Threads), RowsCfg<ROWS>::Lds,
+  hipLaunchKernelGGL((gemm_rows_kernel<ROWS, F8>), dim3(nblocks8 * mblocks, p.splitk), dim3(kR2Threads), RowsCfg<ROWS>::Lds,
                      stream, p);
 }
 
@@ -228,5 +285,11 @@ using namespace dlia;
 // Called by dlia_gemm_skinny for bf16 weights and M > 128; `p` is fully set up (split-K only up to
 // 256 rows).
 extern "C" void dlia_gemm_rows(const dlia::GemmParams* p, hipStream_t stream) {
-  launch_rows<256>(*p, stream);
+  launch_rows<256, false>(*p, stream);
+}
+
+// The same for e4m3 x e4m3 (called by dlia_gemm_a8w8 for M > 128): p->x = e4m3 rows (ldx in
+// bytes), p->xscale per row, p->wp from pack_weight_a8w8, p->wscale per packed row.
+extern "C" void dlia_gemm_rows_f8(const dlia::GemmParams* p, hipStream_t stream) {
+  launch_rows<256, true>(*p, stream);
 }

@@ -331,6 +331,19 @@ def test_gemm_partials_consumed_by_norm_and_rope(K):
         assert_close(o3, ref.rmsnorm(hn[rows.long()], g, 1e-5), 3e-2, 2e-2, "row-gathered norm over partials")
 
 
+@pytest.mark.parametrize("M", [257, 300, 520])
+@pytest.mark.parametrize("epi", [0, 3, 4, 5])
+def test_gemm_a8w8_large_m(K, M, epi):
+    """More than 256 rows in one launch (256-row blocks inside the kernel), row counts that end
+    inside a block."""
+    _gemm_a8w8_case(K, M, 1024, 512, epi, 1)
+
+
+def test_gemm_a8w8_large_m_llama_shape(K):
+    _gemm_a8w8_case(K, 1024, 6144, 4096, 2, 1)
+    _gemm_a8w8_case(K, 512, 1152, 1024, 0, 1, out_f32=True)      # 72 n-tiles: 9 column blocks, grid padded to 16
+
+
 LARGE_KERNELS = {"stream": 2, "big": 1, "tile": 3}     # see the `large_gemm_kernel` op
 
 
