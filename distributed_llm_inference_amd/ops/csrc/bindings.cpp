@@ -276,9 +276,18 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
     if (k == 1)
       dlia_gemm_big(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
                     out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
-    else if (k == 2)
-      dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, nullptr, nullptr, (int)M, (int)N, (int)K,
+    else if (k == 2) {
+      // (a workspace given here is only ever used as the debug buffer of the kernel's diagnostic build)
+      float* dbg = nullptr;
+      if (workspace.has_value()) {
+        check_f32(*workspace, "workspace");
+        const int64_t wgs = ((N + 127) / 128 + 7) / 8 * 8 * ((M + 255) / 256);
+        DLIA_CHECK(workspace->is_contiguous() && workspace->numel() >= wgs * 12 * 8, "debug buffer too small");
+        dbg = workspace->data_ptr<float>();
+      }
+      dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, dbg, nullptr, (int)M, (int)N, (int)K,
                        x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, 1, 2, stream);
+    }
     else
       dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
                      out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);

@@ -28,6 +28,7 @@
 //
 // Replaces the nn.Linear calls inside HF LlamaDecoderLayer that the reference runs on CPU in
 // fp32 (Worker1.py:128-137) and the lm_head (orchestration.py:141).
+#include <cstdlib>
 #include "common.h"
 #include "gemm_common.h"
 #include "launch.h"
@@ -86,7 +87,23 @@ __device__ __forceinline__ const void* r2_sel(bool c, const void* a, const void*
 // fragment, so every byte count, LDS address and wait count below is the same as for bf16; only the
 // chunk covers twice the K and is consumed by v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales,
 // lane l = (r, q) holds k = 32 q .. 32 q + 31 of row r: 16-B slots 2q and 2q + 1 of its x row).
-template <int ROWS, bool F8>
+//
+// DIAG: diagnostic build (DLIA_GEMM_ROWS_DIAG=1, never used for serving). Every wave accumulates
+// s_memtime deltas of the sections of a chunk and lane 0 stores them to p.partial, which then is a
+// debug buffer [workgroup][12 waves][4] of int64 that no other code reads: compute waves
+// {barrier wait, first fragment reads, MFMA section, chunks}, loaders {vmcnt wait, barrier wait,
+// DMA issue, chunks}. The stamps cost ~10 % themselves; ratios are what they are for.
+//
+// What the stamps say (256 x 128 tile, gate/up shape, 256 and 4096 rows alike): a chunk takes
+// ~1400 shader cycles for 1024 cycles of MFMA work per SIMD. Compute waves: ~190 at the barrier,
+// ~240 waiting for their first fragment reads after it, ~710 in the MFMA section. Loaders: ~130
+// waiting for data (it has landed), ~400 at the barrier, ~850 issuing their 12 DMA pieces
+// (~70 cycles a piece). A schedule that lets compute waves prefetch the next chunk before the
+// barrier — loaders guaranteeing chunk c+1 instead of c at barrier c — was tried and ran at 0.88
+// instead of 1.15 PFLOP/s at 4096 rows: it costs one chunk of prefetch distance, and a piece takes
+// longer than one chunk to land. Hiding those reads needs finer stages (32 K-elements, a deeper
+// ring) so that the distance can be kept; LDS has no room for a fourth 32 KiB x stage.
+template <int ROWS, bool F8, bool DIAG = false>
 __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) {
   using C = RowsCfg<ROWS>;
   constexpr int XP = C::XP, MTW = C::MTW, LW = C::LW, WD = C::WD;
@@ -154,15 +171,30 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     xdma(0, 0); wdma(LW - 2, LW - 2);
     xdma(1, min(1, n - 1)); wdma(LW - 1, LW - 1);
     int xs = 0, wsl = 0;
+    long d_vm = 0, d_bar = 0, d_issue = 0;
     for (int c = 0; c < n; ++c) {
+      long t0 = 0, t1 = 0, t2 = 0;
+      if constexpr (DIAG) t0 = __builtin_amdgcn_s_memtime();
       r2_wait_vm<LW >= 3 ? XP + 8 : XP + 4>();
+      if constexpr (DIAG) t1 = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
+      if constexpr (DIAG) t2 = __builtin_amdgcn_s_memtime();
       xdma(xs >= 1 ? xs - 1 : 2, min(c + 2, n - 1));          // stage (c + 2) % 3
       wdma(wsl >= 1 ? wsl - 1 : WD - 1, c + LW);              // slot (c + LW) % WD
       xs = xs == 2 ? 0 : xs + 1;
       wsl = wsl == WD - 1 ? 0 : wsl + 1;
+      if constexpr (DIAG) {
+        const long t3 = __builtin_amdgcn_s_memtime();
+        d_vm += t1 - t0; d_bar += t2 - t1; d_issue += t3 - t2;
+      }
     }
     r2_wait_vm<0>();                                        // no DMA may land after the workgroup is gone
+    if constexpr (DIAG) {
+      if (lane == 0) {
+        long* d = reinterpret_cast<long*>(p.partial) + ((long)blockIdx.x * 12 + wave) * 4;
+        d[0] = d_vm; d[1] = d_bar; d[2] = d_issue; d[3] = n;
+      }
+    }
     return;
   }
 
@@ -181,9 +213,13 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     int xs = 0, wsl = 0;
     const int xoff = (mh * (ROWS / 2) + l15) * 128;
     const int sw = (l15 >> 1) & 7;
+    long d_bar = 0, d_rd = 0, d_mfma = 0;
     for (int c = 0; c < n; ++c) {
+      long t0 = 0, t1 = 0, t2 = 0;
+      if constexpr (DIAG) t0 = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DIAG) t1 = __builtin_amdgcn_s_memtime();
       const char* xb = smem + xs * C::XStage + xoff;
       const char* wb = smem + kR2XS * C::XStage + wsl * kR2WSlot + nq * 4096 + lane * 16;
       xs = xs == 2 ? 0 : xs + 1;
@@ -229,6 +265,11 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
         for (int j = 0; j < 2; ++j) wf[kk][j] = *reinterpret_cast<const u32x4*>(wb + (j * 2 + kk) * 1024);
 #pragma unroll
       for (int i4 = 0; i4 < GS; ++i4) xg[0][i4] = xfrag(i4, 0);
+      if constexpr (DIAG) {                                   // the first fragments have arrived
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        t2 = __builtin_amdgcn_s_memtime();
+      }
 #pragma unroll
       for (int g = 0; g < G; ++g) {                           // (k-step, group of m-tiles)
         const int kk = g / GPK, ig = g % GPK;
@@ -243,6 +284,16 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
             acc[ig * GS + i4][j] = mfma16(wf[kk][j], xg[g & 1][i4], acc[ig * GS + i4][j]);
         __builtin_amdgcn_sched_barrier(0);                    // keep the next group's reads ahead of these MFMAs
       }
+      if constexpr (DIAG) {
+        const long t3 = __builtin_amdgcn_s_memtime();
+        d_bar += t1 - t0; d_rd += t2 - t1; d_mfma += t3 - t2;
+      }
+      }
+    }
+    if constexpr (DIAG) {
+      if (lane == 0) {
+        long* d = reinterpret_cast<long*>(p.partial) + ((long)blockIdx.x * 12 + wave) * 4;
+        d[0] = d_bar; d[1] = d_rd; d[2] = d_mfma; d[3] = n;
       }
     }
   }
@@ -285,6 +336,19 @@ using namespace dlia;
 // Called by dlia_gemm_skinny for bf16 weights and M > 128; `p` is fully set up (split-K only up to
 // 256 rows).
 extern "C" void dlia_gemm_rows(const dlia::GemmParams* p, hipStream_t stream) {
+  static const bool diag = [] { const char* e = getenv("DLIA_GEMM_ROWS_DIAG"); return e && atoi(e) != 0; }();
+  if (diag && p->partial && p->splitk == 1 && !p->partial_only) {       // p->partial = debug buffer, see DIAG
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<256, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RowsCfg<256>::Lds);
+      return true;
+    }();
+    (void)once;
+    const int nblocks8 = (p->ntiles / 8 + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
+    hipLaunchKernelGGL((gemm_rows_kernel<256, false, true>), dim3(nblocks8 * mblocks, 1), dim3(kR2Threads),
+                       RowsCfg<256>::Lds, stream, *p);
+    return;
+  }
   launch_rows<256, false>(*p, stream);
 }
 
