@@ -192,6 +192,26 @@ def _deadline(seconds: float):
     return t
 
 
+def _fit_batch(a, nmb: int, max_seq: int, world: int) -> int:
+    """The KV cache holds every in-flight sequence for prompt + warm-up + timed steps. A long run
+    (--steps in the hundreds) at 2 x 1024 sequences per GPU would ask for more than the device has:
+    halve the micro-batch until the largest stage's share fits in 60 % of device memory, and say so
+    (the size used is reported in the JSON line's config)."""
+    from distributed_llm_inference_amd.parallel.launcher import plans_for, resolve_spec
+    cfg = EngineConfig(model=a.model, pp_size=world, partition=a.partition)
+    spec = resolve_spec(cfg)
+    layers = max(p.layer_end - p.layer_start for p in plans_for(cfg, spec))
+    idx = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    budget = 0.6 * torch.cuda.get_device_properties(idx).total_memory
+    batch = a.batch
+    while batch > 64 and nmb * batch * max_seq * spec.kv_bytes_per_token_per_layer() * layers > budget:
+        batch //= 2
+    if batch != a.batch and int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write(f"bench.py: KV cache for {nmb} x {a.batch} sequences of {max_seq} tokens does not fit; "
+                         f"using micro-batches of {batch}\n")
+    return batch
+
+
 def main():
     a = parse()
     timer = _deadline(a.max_seconds)
@@ -206,6 +226,8 @@ def main():
     a.decode_streams = a.decode_streams or (2 if wide else 3)
     nmb = a.micro_batches or (2 if wide else 3) * max(1, world)
     max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
+    if not a.cpu:
+        a.batch = _fit_batch(a, nmb, max_seq, max(1, world))
     cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
                        use_graphs=not a.no_graph, device="cpu" if a.cpu else "auto",
