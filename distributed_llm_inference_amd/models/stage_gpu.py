@@ -504,7 +504,10 @@ class GpuStage:
         torch.cuda.current_stream(self.device).wait_stream(side)
         st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # Thread-local capture mode: only this thread issues the captured work, but a stage process
+        # of a multi-GPU pipeline also runs RCCL's watchdog thread (event queries at any time), and
+        # under the default global mode a HIP call from another thread invalidates the capture.
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._decode_body(st)
         st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
         st.graph = g
