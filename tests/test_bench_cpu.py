@@ -1,0 +1,87 @@
+"""bench.py's contract with the benchmark driver, exercised on CPU (`--cpu`: torch backend, gloo):
+one JSON line from rank 0 with the agreed keys, whole-job throughput consistent with the timed
+steps, and the same command line under `torch.distributed.run` for N > 1."""
+import importlib.util
+import json
+import os
+import socket
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+KEYS = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": int, "warmup": int, "ms_per_step": float,
+        "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _check(line: str, n: int, steps: int, warmup: int):
+    r = json.loads(line)
+    for k, t in KEYS.items():
+        assert k in r, k
+        assert isinstance(r[k], t) or (t is float and isinstance(r[k], int)), (k, r[k])
+    assert "vs_baseline" in r
+    assert r["n_gpus"] == n and r["steps"] == steps and r["warmup"] == warmup
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["unit"] == "tokens/s"
+    cfg = r["config"]
+    assert cfg["parallelism"] == f"pp{n}" and cfg["seq_len"] == 128
+    assert cfg["global_batch"] == cfg["micro_batches"] * cfg["micro_batch_size"]
+    # value is the whole job: every in-flight sequence emits one token per step
+    want = cfg["global_batch"] / (r["ms_per_step"] * 1e-3)
+    assert abs(r["value"] - want) <= 0.01 * want, (r["value"], want)
+    return r
+
+
+def _json_lines(out: str):
+    return [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+
+
+def test_single_rank_prints_one_json_line():
+    p = subprocess.run([sys.executable, BENCH, "--cpu", "--model", "tiny-llama-test", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    r = _check(lines[0], 1, 3, 1)
+    assert r["config"]["micro_batches"] == 2           # 2 x gpus
+
+
+def test_two_ranks_under_torch_distributed_run():
+    """The driver's N > 1 launch line: one rank per stage, rank 0 prints the line, the others none."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--cpu", "--gpus", "2",
+                        "--model", "tiny-llama-test", "--steps", "3", "--warmup", "1", "--max-seconds", "240"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    r = _check(lines[0], 2, 3, 1)
+    assert r["config"]["micro_batches"] == 4 and len(r["config"]["layer_ranges"]) == 2
+
+
+def test_micro_batch_shrinks_when_the_kv_cache_would_not_fit(monkeypatch):
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    spec.loader.exec_module(b)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(total_memory=288 * 2 ** 30))
+
+    def fit(steps, world):
+        a = types.SimpleNamespace(model="llama-3-8b", partition="balanced", batch=1024, prompt_len=128, steps=steps, warmup=4)
+        max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
+        return b._fit_batch(a, 2 * world, max_seq, world)
+
+    assert fit(32, 1) == 1024 and fit(32, 8) == 1024        # the driver's default fits at every N
+    assert fit(1000, 1) == 512                              # 2 x 1024 x 1152 tokens x 128 KiB = 309 GB does not
+    assert fit(1000, 8) < 1024
