@@ -173,7 +173,8 @@ void rope_kvwrite(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias
 }
 
 // Kernel for bf16 GEMMs of more than 256 rows: 0 = default (2), 1 = 256 x 256 tiles, 2 = the streaming
-// kernel walking 256-row blocks, 3 = 128 x 128 tiles. Starts from DLIA_GEMM_LARGE (big / stream /
+// kernel walking 256-row blocks, 3 = 128 x 128 tiles, 4 = the streaming kernel with 128- / 64-row blocks on
+// shapes with few column blocks (this one also applies to the fp8 x fp8 GEMM). Starts from DLIA_GEMM_LARGE (big / stream /
 // tile); the `large_gemm_kernel` op changes it for A/B runs and tests.
 static std::atomic<int>& large_gemm_choice() {
   static std::atomic<int> v{[] {
@@ -184,8 +185,10 @@ static std::atomic<int>& large_gemm_choice() {
   return v;
 }
 int64_t large_gemm_kernel(int64_t which) {
-  DLIA_CHECK(which >= 0 && which <= 3, "large_gemm_kernel: 0 default, 1 big, 2 stream, 3 tile");
-  return large_gemm_choice().exchange((int)which);
+  DLIA_CHECK(which >= 0 && which <= 4, "large_gemm_kernel: 0 default, 1 big, 2 stream, 3 tile, 4 stream with narrow row blocks");
+  const int narrow_before = dlia_gemm_rows_set_narrow(which == 4 ? 1 : 0);
+  const int before = large_gemm_choice().exchange(which == 4 ? 2 : (int)which);
+  return (before == 2 || before == 0) && narrow_before ? 4 : before;
 }
 
 // out[M, N_out] = epi(x[M,K] @ W^T); wp = packed weights (uint8 view of the packed image).

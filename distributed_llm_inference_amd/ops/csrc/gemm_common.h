@@ -106,6 +106,7 @@ __device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc
 extern "C" void dlia_splitk_reduce(const dlia::GemmParams* p, hipStream_t stream);
 extern "C" void dlia_gemm_rows(const dlia::GemmParams* p, hipStream_t stream);
 extern "C" void dlia_gemm_rows_f8(const dlia::GemmParams* p, hipStream_t stream);
+extern "C" int dlia_gemm_rows_set_narrow(int on);
 extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_split, int* ntw_out, int* splitk_out);
 namespace dlia {
 

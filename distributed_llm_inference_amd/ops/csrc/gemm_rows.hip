@@ -18,7 +18,7 @@
 //    instead of 59 (a wave blocked in a full memory queue issues no MFMAs).
 // The kernel is written for any ROWS in {32, 64, 128, 256} per workgroup (fewer rows shrink the x
 // stages and deepen the weight ring to 5-7 chunks), and those variants pass the numerics tests,
-// but only ROWS = 256 is launched: measured at 1 / 64 / 128 rows a decode step takes 3.73 / 4.30 /
+// but up to 256 rows only ROWS = 256 is launched: measured at 1 / 64 / 128 rows a decode step takes 3.73 / 4.30 /
 // 5.41 ms with them against 3.58 / 4.31 / 5.41 ms with the register-ring kernels of
 // gemm_skinny.hip, which already stream the large shapes at the HBM ceiling there (gate/up
 // 5.3 TB/s at 64 rows) — a deeper ring has nothing left to hide.
@@ -28,6 +28,7 @@
 //
 // Replaces the nn.Linear calls inside HF LlamaDecoderLayer that the reference runs on CPU in
 // fp32 (Worker1.py:128-137) and the lm_head (orchestration.py:141).
+#include <atomic>
 #include <cstdlib>
 #include "common.h"
 #include "gemm_common.h"
@@ -111,12 +112,12 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, quad = lane >> 4;
-  // More than 256 rows: the grid also walks 256-row blocks. Workgroup ids go round-robin over the
+  // More rows than ROWS: the grid also walks ROWS-row blocks. Workgroup ids go round-robin over the
   // 8 XCDs, so the row blocks of one column block get ids that differ by multiples of 8: they run
   // on the same XCD at about the same time and share each weight byte through its L2.
-  const int mblocks = ROWS == 256 ? (p.M + 255) >> 8 : 1;
+  const int mblocks = (p.M + ROWS - 1) / ROWS;
   const int within = blockIdx.x >> 3;
-  const int nblk = (within / mblocks) * 8 + (blockIdx.x & 7), mrow0 = (within % mblocks) * 256;
+  const int nblk = (within / mblocks) * 8 + (blockIdx.x & 7), mrow0 = (within % mblocks) * ROWS;
   const int ks = blockIdx.y;
   if (nblk * 8 >= p.ntiles) return;                         // grid padded to a multiple of 8 column blocks
   const int chunks_total = p.K >> (F8 ? 7 : 6);             // chunk = 128 bytes of an x row
@@ -324,9 +325,30 @@ static void launch_rows(const GemmParams& p, hipStream_t stream) {
     return true;
   }();
   (void)once;
-  const int nblocks8 = (p.ntiles / 8 + 7) / 8 * 8, mblocks = ROWS == 256 ? (p.M + 255) / 256 : 1;
+  const int nblocks8 = (p.ntiles / 8 + 7) / 8 * 8, mblocks = (p.M + ROWS - 1) / ROWS;
   hipLaunchKernelGGL((gemm_rows_kernel<ROWS, F8>), dim3(nblocks8 * mblocks, p.splitk), dim3(kR2Threads), RowsCfg<ROWS>::Lds,
                      stream, p);
+}
+
+// Row-block size for more than 256 rows. 256-row blocks do the most work per DMA byte, but a shape
+// with few column blocks then launches few workgroups (Llama-3-8B O / down projections at 1024
+// rows: 32 column blocks x 4 row blocks = 128 for 256 CUs). Smaller blocks multiply the workgroups;
+// the "narrow" policy takes the largest block that still gives ~200 workgroups. Measured: a GEMM
+// running ALONE gains (layer total at 512 / 1024 rows 398 -> 284 / 513 -> 437 us), but the serving
+// path runs two or three micro-batches on separate streams, and there the narrow launch that left
+// half the CUs to the other stream's kernels was the better one: bench.py 3 x 512 rows 53.3k ->
+// 44.0k tok/s, 2 x 1024 rows 56k -> 54k with the policy on. So it is OFF unless selected
+// (DLIA_GEMM_ROWS_NARROW=1, or dlia_gemm_rows_set_narrow / the large_gemm_kernel op at run time).
+static std::atomic<int>& narrow_policy() {
+  static std::atomic<int> v{[] { const char* e = getenv("DLIA_GEMM_ROWS_NARROW"); return (e && atoi(e) != 0) ? 1 : 0; }()};
+  return v;
+}
+static int row_block(const GemmParams& p) {
+  if (!narrow_policy().load() || p.M <= 256) return 256;
+  const int nb = p.ntiles / 8;
+  if (nb * ((p.M + 255) / 256) > 160) return 256;
+  if (nb * ((p.M + 127) / 128) > 160) return 128;
+  return 64;
 }
 
 }  // namespace dlia
@@ -349,11 +371,22 @@ extern "C" void dlia_gemm_rows(const dlia::GemmParams* p, hipStream_t stream) {
                        RowsCfg<256>::Lds, stream, *p);
     return;
   }
-  launch_rows<256, false>(*p, stream);
+  switch (row_block(*p)) {
+    case 64:  launch_rows<64, false>(*p, stream); break;
+    case 128: launch_rows<128, false>(*p, stream); break;
+    default:  launch_rows<256, false>(*p, stream);
+  }
 }
 
 // The same for e4m3 x e4m3 (called by dlia_gemm_a8w8 for M > 128): p->x = e4m3 rows (ldx in
 // bytes), p->xscale per row, p->wp from pack_weight_a8w8, p->wscale per packed row.
 extern "C" void dlia_gemm_rows_f8(const dlia::GemmParams* p, hipStream_t stream) {
-  launch_rows<256, true>(*p, stream);
+  switch (row_block(*p)) {
+    case 64:  launch_rows<64, true>(*p, stream); break;
+    case 128: launch_rows<128, true>(*p, stream); break;
+    default:  launch_rows<256, true>(*p, stream);
+  }
 }
+
+// 1: pick 128- / 64-row blocks for shapes with few column blocks (see row_block); returns the old value.
+extern "C" int dlia_gemm_rows_set_narrow(int on) { return narrow_policy().exchange(on ? 1 : 0); }

@@ -61,6 +61,8 @@ void dlia_gemm_tile(void* out, const void* x, const void* wp, const void* bias,
 void dlia_gemm_big(void* out, const void* x, const void* wp, const void* bias,
                     const void* residual, int M, int N, int K, long ldx, long ldo, long ldr,
                     int epi, int out_f32, hipStream_t stream);
+// 1: the streaming GEMM picks 128- / 64-row blocks on shapes with few column blocks (off by default); returns the old value
+int dlia_gemm_rows_set_narrow(int on);
 
 // ---- attention.hip --------------------------------------------------------------------
 // Causal GQA attention of ragged query chunks against the paged KV cache (prefill chunks and

@@ -367,6 +367,22 @@ def test_gemm_large_m_llama_shape(K, large_kernel):
     _gemm_case(K, 1024, 6144, 4096, 2, 1)
 
 
+def test_gemm_large_m_row_block_tiers(K):
+    """With the narrow policy the streaming kernel walks 256-, 128- or 64-row blocks, whichever is the
+    largest that still launches ~200 workgroups. N = 4096 (32 column blocks): 700 and 1024 rows take 128-row blocks
+    (700 ends inside one), 400 rows take 64-row blocks, 1500 rows 256-row blocks."""
+    prev = K.large_gemm_kernel(4)          # streaming kernel, narrow row-block policy on (off by default)
+    try:
+        for M in (700, 1024, 400, 1500):
+            _gemm_case(K, M, 4096, 512, 2, 1)
+        _gemm_case(K, 700, 4096, 512, 4, 1)
+        _gemm_case(K, 300, 1024, 512, 3, 1)
+        for M in (700, 400, 1500):
+            _gemm_a8w8_case(K, M, 4096, 512, 2, 1)
+    finally:
+        K.large_gemm_kernel(prev)
+
+
 def test_gemm_large_m_column_blocks_not_a_multiple_of_256(K, large_kernel):
     """N = 1152 packs to 72 n-tiles = 4.5 blocks of 256 columns: the last workgroup of the 256 x 256
     kernel has only half a block of real weight tiles."""
