@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"],
                     help="fp8: decoder-layer GEMMs on the fp8 MFMA (e4m3 weights + per-row quantised activations); "
                          "fp8w: e4m3 weights only; KV cache and lm_head stay bf16 in both")
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: e4m3 KV cache with per-(token, head) scales (half the attention bytes; not the default)")
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "gloo"],
                     help="activation transport between stages (auto: RCCL on GPUs; gloo = host-staged TCP, which "
                          "also lets several stages share one GPU for a rehearsal)")
@@ -204,7 +206,7 @@ def _fit_batch(a, nmb: int, max_seq: int, world: int) -> int:
     idx = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     budget = 0.6 * torch.cuda.get_device_properties(idx).total_memory
     batch = a.batch
-    while batch > 64 and nmb * batch * max_seq * spec.kv_bytes_per_token_per_layer() * layers > budget:
+    while batch > 64 and nmb * batch * max_seq * spec.kv_bytes_per_token_per_layer(1 if a.kv_dtype == "fp8" else 2) * layers > budget:
         batch //= 2
     if batch != a.batch and int(os.environ.get("RANK", "0")) == 0:
         sys.stderr.write(f"bench.py: KV cache for {nmb} x {a.batch} sequences of {max_seq} tokens does not fit; "
@@ -232,7 +234,7 @@ def main():
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
                        use_graphs=not a.no_graph, device="cpu" if a.cpu else "auto",
                        backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype, decode_streams=a.decode_streams,
-                       transport="gloo" if a.cpu else a.transport)
+                       transport="gloo" if a.cpu else a.transport, kv_dtype="bf16" if a.cpu else a.kv_dtype)
     rank, world, rt, board, spec, cfg = attach_distributed(cfg)
     if rank != 0:
         stage_main(rt)
@@ -286,7 +288,7 @@ def main():
                        "parallelism": f"pp{world}", "micro_batches": cfg.num_micro_batches,
                        "micro_batch_size": cfg.max_batch, "layer_ranges": plans,
                        "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": cfg.use_graphs, "decode_streams": cfg.decode_streams,
-                       "backend": rt.ex.backend, "transport": cfg.resolved_transport()}}), flush=True)
+                       "backend": rt.ex.backend, "transport": cfg.resolved_transport(), "kv_cache": cfg.kv_dtype}}), flush=True)
     if world > 1:
         import torch.distributed as dist
         try:

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"])
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 KV cache with per-(token, head) scales")
     a = ap.parse_args()
     spec = ModelSpec.from_pretrained(a.model)
     if a.layers:
@@ -35,7 +36,7 @@ def main():
     per = T // B
     nblk = (per + 31) // 32 + 1
     st = GpuStage(spec, plan, w, max_slots=B, max_seq_len=nblk * 32, num_blocks=B * nblk, max_tokens=T, max_batch=max(B, 8),
-                  use_graphs=False, weight_dtype=a.dtype)
+                  use_graphs=False, weight_dtype=a.dtype, kv_dtype=a.kv_dtype)
     del w
     tables = {s: list(range(s * nblk, (s + 1) * nblk)) for s in range(B)}
     ids = torch.randint(10, spec.vocab_size - 10, (per * B,), dtype=torch.int32)

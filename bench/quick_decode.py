@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="truncate the model (profiling)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"])
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 KV cache with per-(token, head) scales")
     a = ap.parse_args()
     spec = ModelSpec.from_pretrained(a.model)
     if a.layers:
@@ -38,7 +39,7 @@ def main():
     max_len = a.ctx + a.steps + a.warmup + 8
     nblk = (max_len + 31) // 32
     st = GpuStage(spec, plan, w, max_slots=B, max_seq_len=nblk * 32, num_blocks=B * nblk, max_tokens=max(B, 64),
-                  max_batch=B, use_graphs=not a.no_graph, weight_dtype=a.dtype)
+                  max_batch=B, use_graphs=not a.no_graph, weight_dtype=a.dtype, kv_dtype=a.kv_dtype)
     del w
     torch.cuda.synchronize()
     print(f"built in {time.time() - t0:.1f}s", st.memory_report(), flush=True)

@@ -20,6 +20,7 @@ class EngineConfig:
     model: str = "tinyllama-1.1b"          # built-in name or HF checkpoint directory
     weights: str = "auto"                  # "auto": checkpoint if `model` is a dir with weights, else random
     dtype: str = "bf16"                    # bf16 | fp8 (e4m3 weights x e4m3 activations on the fp8 MFMA) | fp8w (e4m3 weights only)
+    kv_dtype: str = "bf16"                 # bf16 | fp8 (e4m3 KV cache with one scale per token and kv head; HIP backend)
     seed: int = 0                          # random-init seed
     tokenizer: Optional[str] = None        # tokenizer directory (default: the model directory; else byte fallback)
     # ---- pipeline ----------------------------------------------------------------------
@@ -70,6 +71,8 @@ class EngineConfig:
             self.partition = "explicit"
         if self.dtype not in ("bf16", "fp32", "fp8", "fp8w"):
             raise ValueError(f"unsupported dtype {self.dtype!r}")
+        if self.kv_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"unsupported kv_dtype {self.kv_dtype!r}")
         if self.max_batch < 1 or self.max_seq_len < 8:
             raise ValueError("max_batch / max_seq_len out of range")
 

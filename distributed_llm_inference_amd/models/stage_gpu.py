@@ -80,13 +80,16 @@ class GpuStage:
     def __init__(self, spec: ModelSpec, plan: StagePlan, weights: StageWeights, *, device="cuda",
                  max_slots: int = 256, max_seq_len: int = 2048, num_blocks: Optional[int] = None,
                  max_tokens: int = 2048, max_batch: int = 64, use_graphs: bool = True,
-                 kv_mem_fraction: float = 0.85, weight_dtype: str = "bf16"):
+                 kv_mem_fraction: float = 0.85, weight_dtype: str = "bf16", kv_dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
         if spec.head_dim not in (64, 128):
             raise ValueError("the HIP attention kernels support head_dim 64 and 128")
         if weight_dtype not in ("bf16", "fp8", "fp8w"):
             raise ValueError("weight_dtype must be bf16, fp8 or fp8w")
+        if kv_dtype not in ("bf16", "fp8"):
+            raise ValueError("kv_dtype must be bf16 or fp8")
+        self.kv8 = kv_dtype == "fp8"
         self.K = ops.load()
         # decoder-layer GEMMs: "fp8" = e4m3 weights (per-channel scale) x e4m3 activations (per-row
         # dynamic scale) on the block-scaled fp8 MFMA; "fp8w" = e4m3 weights widened to bf16 in
@@ -135,7 +138,8 @@ class GpuStage:
 
         # ---- paged KV cache for this stage's layers ---------------------------------------
         L = plan.num_layers
-        blk_bytes = L * spec.num_kv_heads * 2 * BLOCK * spec.head_dim * 2
+        # bytes of one block over this stage's layers (e4m3: 1 byte per element + a fp32 scale per token, head, K|V)
+        blk_bytes = L * spec.num_kv_heads * 2 * BLOCK * (spec.head_dim + 4 if self.kv8 else spec.head_dim * 2)
         if num_blocks is None:
             free, _ = torch.cuda.mem_get_info(dev)
             budget = int(free * kv_mem_fraction) - self._workspace_bytes()
@@ -143,7 +147,9 @@ class GpuStage:
         self.num_blocks = int(num_blocks)
         # zero-filled: masked-out (never written) slots must hold finite values, P=0 times NaN is NaN
         self.kv = torch.zeros(max(L, 1), self.num_blocks, spec.num_kv_heads, 2, BLOCK * spec.head_dim,
-                              device=dev, dtype=bf)
+                              device=dev, dtype=torch.uint8 if self.kv8 else bf)
+        self.kv_scale = (torch.zeros(max(L, 1), self.num_blocks, spec.num_kv_heads, 2, BLOCK, device=dev)
+                         if self.kv8 else None)
         self.block_table = torch.full((max_slots + 1, self.max_blocks), -1, device=dev, dtype=torch.int32)
 
         # ---- activation workspaces ----------------------------------------------------------
@@ -211,6 +217,24 @@ class GpuStage:
             self.K.quant_rows(xq, wk.xs, x)
             self.K.gemm_a8w8(out, xq, wk.xs, p[name], sc, bias, residual, ws, N, epi, splitk, min(ntw, 2))
 
+    def _kvwrite(self, li, qkv, part, S, pbias, tok_pos, tok_seq):
+        s = self.spec
+        if self.kv8:
+            self.K.rope_kvwrite8(qkv, part, S, pbias, self.kv[li], self.kv_scale[li], self.cos, self.sin, tok_pos, tok_seq,
+                                 self.block_table, s.num_heads, s.num_kv_heads, s.head_dim, s.is_llama)
+        else:
+            self.K.rope_kvwrite(qkv, part, S, pbias, self.kv[li], self.cos, self.sin, tok_pos, tok_seq,
+                                self.block_table, s.num_heads, s.num_kv_heads, s.head_dim, s.is_llama)
+
+    def _attention(self, li, attn, qkv, q_start, ctx, slots, partial, max_q, splits):
+        s = self.spec
+        if self.kv8:
+            self.K.paged_attention8(attn, qkv, self.kv[li], self.kv_scale[li], q_start, ctx, self.block_table, slots, partial,
+                                    max_q, s.num_heads, s.num_kv_heads, s.head_dim, self.scale, splits)
+        else:
+            self.K.paged_attention(attn, qkv, self.kv[li], q_start, ctx, self.block_table, slots, partial,
+                                   max_q, s.num_heads, s.num_kv_heads, s.head_dim, self.scale, splits)
+
     def _workspace_bytes(self) -> int:
         s = self.spec
         per_tok = 2 * (2 * s.hidden_size + s.qkv_size + s.q_size + s.intermediate_size)
@@ -264,13 +288,10 @@ class GpuStage:
         if T > DECODE_ROWS:
             # prefill regime: tiled MFMA GEMMs with fused bias / residual / activation epilogues
             for li, p in enumerate(self.layers):
-                kv = self.kv[li]
                 x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
                 self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
-                K.rope_kvwrite(qkv, None, 1, None, kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
-                               Hq, Hkv, D, llama)
-                K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
-                                  self.scale, splits)
+                self._kvwrite(li, qkv, None, 1, None, tok_pos, tok_seq)
+                self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
                 self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
                 x2 = norm(None, 1, None, p["ln2_w"], p.get("ln2_b"))
                 if llama:
@@ -288,16 +309,13 @@ class GpuStage:
         nd, sd = self._cfg(T, H, I, 6)
         pend = None
         for li, p in enumerate(self.layers):
-            kv = self.kv[li]
             if pend is None:
                 x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
             else:
                 x1 = norm(ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"))
             self._gemm(wk, qkv, x1, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
-            K.rope_kvwrite(qkv, ws, sq, p.get("b_qkv"), kv, self.cos, self.sin, tok_pos, tok_seq, self.block_table,
-                           Hq, Hkv, D, llama)
-            K.paged_attention(attn, qkv, kv, q_start, ctx, self.block_table, slots, partial, max_q, Hq, Hkv, D,
-                              self.scale, splits)
+            self._kvwrite(li, qkv, ws, sq, p.get("b_qkv"), tok_pos, tok_seq)
+            self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
             self._gemm(wk, h, attn, p, "w_o", None, None, ws, H, 6, so, no)
             x2 = norm(ws, so, p.get("b_o"), p["ln2_w"], p.get("ln2_b"))
             if llama:
@@ -519,5 +537,5 @@ class GpuStage:
         for t in (self.embed, self.pos_embed, getattr(self, "lm_head", None)):
             if t is not None:
                 wbytes += t.numel() * t.element_size()
-        return {"weights_gib": wbytes / gib, "kv_gib": self.kv.numel() * 2 / gib, "kv_blocks": self.num_blocks,
+        return {"weights_gib": wbytes / gib, "kv_gib": (self.kv.numel() * self.kv.element_size() + (self.kv_scale.numel() * 4 if self.kv8 else 0)) / gib, "kv_blocks": self.num_blocks,
                 "kv_tokens": self.num_blocks * BLOCK}

@@ -16,6 +16,12 @@
 //                                               to match), B = P^T = the S^T accumulator
 //                                               registers packed to bf16, no data movement
 //
+// KV8: the cache holds OCP e4m3 bytes + one fp32 scale per (token, kv head, K|V) (kv_layout.h). A
+// 16-byte lane load carries two fragments, which are widened to bf16 in registers (exact) right
+// before use, so a block costs half the HBM bytes and half the load instructions, and the
+// prefetch buffers half the registers. The K scale of a key multiplies its row of S^T; the V scale
+// is folded into P^T (the softmax sum uses the unscaled probabilities).
+//
 // Split-KV (decode with few sequences / long contexts): each split writes unnormalised
 // (m, l, O) per column and a second kernel merges them.
 //
@@ -30,7 +36,8 @@ namespace dlia {
 struct AttnParams {
   bf16* out; long ldo;            // [T, Hq*D]
   const bf16* q; long ldq;        // q rows (post-RoPE) inside the fused qkv activation
-  const bf16* kv;                 // this layer's cache
+  const bf16* kv;                 // this layer's cache (bf16, or e4m3 bytes when kv_scale is set)
+  const float* kv_scale;          // [blocks][Hkv][2][32] or null
   const int* q_start;             // [B+1] first token row of each sequence's chunk
   const int* ctx_lens;            // [B] tokens already cached before this chunk
   const int* block_table;         // [table_rows, max_blocks]
@@ -44,7 +51,7 @@ struct AttnParams {
 
 constexpr float kNegInf = -__builtin_inff();
 
-template <int D, int NT>
+template <int D, int NT, bool KV8>
 __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
   constexpr int KS = D / 32;      // MFMA k-steps over the head dim (QK^T)
   constexpr int DT = D / 16;      // 16-row tiles of the head dim (PV)
@@ -117,32 +124,69 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
 
   const long slab = kv_slab_elems(D);
   const int* table = p.block_table + (long)srow * p.max_blocks;
-  auto block_base = [&](int kb) -> const bf16* {
-    int blk = table[kb];
-    blk = (srow_ok && blk >= 0 && blk < p.num_blocks) ? blk : 0;          // never a wild read
-    return p.kv + kv_head_base(blk, kvh, p.Hkv, D, 0) + lane * 8;
+  auto block_of = [&](int kb) -> int {
+    const int blk = table[kb];
+    return (srow_ok && blk >= 0 && blk < p.num_blocks) ? blk : 0;          // never a wild read
   };
-  auto load_kv = [&](const bf16* kbase, u32x4 (&kf)[2][KS], u32x4 (&vf)[DT]) {
+  // One block's operands as loaded. bf16: the fragments themselves. KV8: 16-byte loads holding two
+  // fragments each, plus this lane's 8 key scales (keys 16 kt + 4 quad + r) for K and for V.
+  struct Raw {
+    u32x4 k[2][KV8 ? KS / 2 : KS];
+    u32x4 v[KV8 ? DT / 2 : DT];
+    f32x4 sk[2], sv[2];
+  };
+  auto load_kv = [&](int kb, Raw& r) {
+    const int blk = block_of(kb);
+    if constexpr (KV8) {
+      const unsigned char* kbase = reinterpret_cast<const unsigned char*>(p.kv) + kv_head_base(blk, kvh, p.Hkv, D, 0) + lane * 16;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int s = 0; s < KS; ++s) kf[kt][s] = ld16(kbase + kt * 16 * D + s * 512);
+        for (int t = 0; t < KS / 2; ++t) r.k[kt][t] = *reinterpret_cast<const u32x4*>(kbase + (kt * (KS / 2) + t) * 1024);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) vf[dt] = ld16(kbase + slab + dt * 512);
+      for (int t = 0; t < DT / 2; ++t) r.v[t] = *reinterpret_cast<const u32x4*>(kbase + slab + t * 1024);
+      const float* sb = p.kv_scale + kv_scale_base(blk, kvh, p.Hkv, 0) + quad * 4;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        r.sk[kt] = *reinterpret_cast<const f32x4*>(sb + kt * 16);
+        r.sv[kt] = *reinterpret_cast<const f32x4*>(sb + kBlockTokens + kt * 16);
+      }
+    } else {
+      const bf16* kbase = p.kv + kv_head_base(blk, kvh, p.Hkv, D, 0) + lane * 8;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) r.k[kt][s] = ld16(kbase + kt * 16 * D + s * 512);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) r.v[dt] = ld16(kbase + slab + dt * 512);
+    }
   };
 
-  auto process = [&](int kb, const u32x4 (&kf)[2][KS], const u32x4 (&vf)[DT]) {
+  auto process = [&](int kb, const Raw& raw) {
+    auto kfrag = [&](int kt, int s) -> u32x4 {
+      if constexpr (KV8) return fp8x8_to_bf16x8(raw.k[kt][s >> 1][(s & 1) * 2], raw.k[kt][s >> 1][(s & 1) * 2 + 1]);
+      else return raw.k[kt][s];
+    };
+    auto vfrag = [&](int dt) -> u32x4 {
+      if constexpr (KV8) return fp8x8_to_bf16x8(raw.v[dt >> 1][(dt & 1) * 2], raw.v[dt >> 1][(dt & 1) * 2 + 1]);
+      else return raw.v[dt];
+    };
     // S^T = K Q^T : st[kt][nt][r] = score(key = kb*32 + kt*16 + quad*4 + r, column nt*16+l15)
     f32x4 st[2][NT];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt) {
+      u32x4 kf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kf[s] = kfrag(kt, s);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a = mfma16(kf[kt][s], qf[nt][s], a);
+        for (int s = 0; s < KS; ++s) a = mfma16(kf[s], qf[nt][s], a);
+        if constexpr (KV8) a *= raw.sk[kt];
         st[kt][nt] = a;
       }
+    }
     u32x4 pf[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -169,8 +213,8 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float e = exp2f((st[kt][nt][r] - m_safe) * p.scale_log2);
-          pv[kt * 4 + r] = e;
           rs += e;
+          pv[kt * 4 + r] = KV8 ? e * raw.sv[kt][r] : e;       // V's per-key scale rides in P^T
         }
       l[nt] = l[nt] * alpha + rs;
 #pragma unroll
@@ -178,28 +222,30 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
       pf[nt] = pack8(pv);     // element j: key 16*(j>>2) + 4*quad + (j&3) — the V slab's key order
     }
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt) {
+      const u32x4 vf = vfrag(dt);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) o[dt][nt] = mfma16(vf[dt], pf[nt], o[dt][nt]);
+      for (int nt = 0; nt < NT; ++nt) o[dt][nt] = mfma16(vf, pf[nt], o[dt][nt]);
+    }
   };
 
   if constexpr (PREFETCH) {
-    u32x4 kfa[2][KS], vfa[DT], kfb[2][KS], vfb[DT];
+    Raw ra, rb;
     int kb = kb0 + wave;
-    if (kb < kb1) load_kv(block_base(kb), kfa, vfa);
+    if (kb < kb1) load_kv(kb, ra);
     for (; kb < kb1; kb += 8) {
-      if (kb + 4 < kb1) load_kv(block_base(kb + 4), kfb, vfb);
-      process(kb, kfa, vfa);
+      if (kb + 4 < kb1) load_kv(kb + 4, rb);
+      process(kb, ra);
       if (kb + 4 < kb1) {
-        if (kb + 8 < kb1) load_kv(block_base(kb + 8), kfa, vfa);
-        process(kb + 4, kfb, vfb);
+        if (kb + 8 < kb1) load_kv(kb + 8, ra);
+        process(kb + 4, rb);
       }
     }
   } else {
     for (int kb = kb0 + wave; kb < kb1; kb += 4) {
-      u32x4 kf[2][KS], vf[DT];
-      load_kv(block_base(kb), kf, vf);
-      process(kb, kf, vf);
+      Raw r;
+      load_kv(kb, r);
+      process(kb, r);
     }
   }
 
@@ -298,7 +344,8 @@ template <int D, int NT>
 static void launch_attn(const AttnParams& p, hipStream_t stream) {
   const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
   constexpr size_t smem = 4 * NT * 64 * 2 * 4 + 4 * (D / 16) * NT * 64 * 16;
-  hipLaunchKernelGGL((paged_attn_kernel<D, NT>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
+  if (p.kv_scale) hipLaunchKernelGGL((paged_attn_kernel<D, NT, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
+  else            hipLaunchKernelGGL((paged_attn_kernel<D, NT, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   if (p.splits > 1)
     hipLaunchKernelGGL((attn_combine_kernel<D, NT>), dim3((unsigned)((long)p.B * p.Hkv * p.qtiles)), dim3(256), 0,
                        stream, p);
@@ -320,14 +367,14 @@ extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int
   return (long)B * Hkv * qtiles * splits * nt * 16 * (D + 4);
 }
 
-extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache,
+extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache, const float* kv_scale,
                                      const int* q_start, const int* ctx_lens, const int* block_table,
                                      const int* slots, float* partial, int B, int max_q_len, int Hq,
                                      int Hkv, int D, int table_rows, int max_blocks, int num_blocks,
                                      long ldq, long ldo, float scale, int splits, hipStream_t stream) {
   if (B <= 0 || max_q_len <= 0) return;
   AttnParams p;
-  p.out = (bf16*)out; p.ldo = ldo; p.q = (const bf16*)qkv; p.ldq = ldq; p.kv = (const bf16*)kv_cache;
+  p.out = (bf16*)out; p.ldo = ldo; p.q = (const bf16*)qkv; p.ldq = ldq; p.kv = (const bf16*)kv_cache; p.kv_scale = kv_scale;
   p.q_start = q_start; p.ctx_lens = ctx_lens; p.block_table = block_table; p.slots = slots; p.table_rows = table_rows; p.partial = partial;
   p.B = B; p.Hq = Hq; p.Hkv = Hkv;
   const int g = Hq / Hkv;

@@ -137,15 +137,28 @@ inline KvGeom check_kv(const Tensor& kv, int64_t Hkv, int64_t D) {
   return {kv.size(0)};
 }
 
-void rope_kvwrite(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias, Tensor kv_cache,
-                  const Tensor& cos_t, const Tensor& sin_t,
-                  const Tensor& tok_pos, const Tensor& tok_seq, const Tensor& block_table,
-                  int64_t Hq, int64_t Hkv, int64_t D, bool use_rope) {
+// e4m3 cache: bytes [num_blocks, Hkv, 2, 32*D] + fp32 scales [num_blocks, Hkv, 2, 32]
+inline KvGeom check_kv8(const Tensor& kv, const Tensor& kv_scale, int64_t Hkv, int64_t D) {
+  check_dev(kv, "kv_cache"); check_f32(kv_scale, "kv_scale");
+  DLIA_CHECK(kv.scalar_type() == at::kByte, "fp8 kv_cache must be uint8");
+  DLIA_CHECK(kv.is_contiguous() && kv.dim() == 4 && kv.size(1) == Hkv && kv.size(2) == 2 && kv.size(3) == 32 * D,
+             "fp8 kv_cache must be [num_blocks, Hkv, 2, 32*D] bytes");
+  DLIA_CHECK(kv_scale.is_contiguous() && kv_scale.dim() == 4 && kv_scale.size(0) == kv.size(0) && kv_scale.size(1) == Hkv &&
+             kv_scale.size(2) == 2 && kv_scale.size(3) == 32, "kv_scale must be [num_blocks, Hkv, 2, 32]");
+  DLIA_CHECK(reinterpret_cast<uintptr_t>(kv.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(kv_scale.data_ptr()) % 16 == 0,
+             "kv cache alignment");
+  return {kv.size(0)};
+}
+
+static void rope_kvwrite_impl(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias, Tensor kv_cache,
+                              OptTensor kv_scale, const Tensor& cos_t, const Tensor& sin_t,
+                              const Tensor& tok_pos, const Tensor& tok_seq, const Tensor& block_table,
+                              int64_t Hq, int64_t Hkv, int64_t D, bool use_rope) {
   check_bf16(qkv, "qkv");
   DLIA_CHECK(qkv.dim() == 2 && qkv.is_contiguous() && qkv.size(1) == (Hq + 2 * Hkv) * D, "qkv must be [T,(Hq+2Hkv)*D]");
   DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
   const int64_t T = qkv.size(0);
-  auto g = check_kv(kv_cache, Hkv, D);
+  auto g = kv_scale.has_value() ? check_kv8(kv_cache, *kv_scale, Hkv, D) : check_kv(kv_cache, Hkv, D);
   check_i32(tok_pos, "tok_pos"); check_i32(tok_seq, "tok_seq"); check_i32(block_table, "block_table");
   DLIA_CHECK(tok_pos.numel() >= T && tok_seq.numel() >= T && block_table.dim() == 2, "rope_kvwrite: metadata shapes");
   int rope_len = 1;
@@ -167,9 +180,25 @@ void rope_kvwrite(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias
     }
   }
   // tok_seq values index block_table rows: the caller guarantees tok_seq < block_table.size(0)
-  dlia_rope_kvwrite(qkv.data_ptr(), pp, (int)splits, pb, kv_cache.data_ptr(), cp, sp, tok_pos.data_ptr<int>(), tok_seq.data_ptr<int>(),
-                    block_table.data_ptr<int>(), (int)T, (int)Hq, (int)Hkv, (int)D, (int)block_table.size(1),
-                    (int)g.num_blocks, rope_len, use_rope ? 1 : 0, cur_stream());
+  dlia_rope_kvwrite(qkv.data_ptr(), pp, (int)splits, pb, kv_cache.data_ptr(),
+                    kv_scale.has_value() ? kv_scale->data_ptr<float>() : nullptr, cp, sp, tok_pos.data_ptr<int>(),
+                    tok_seq.data_ptr<int>(), block_table.data_ptr<int>(), (int)T, (int)Hq, (int)Hkv, (int)D,
+                    (int)block_table.size(1), (int)g.num_blocks, rope_len, use_rope ? 1 : 0, cur_stream());
+}
+
+void rope_kvwrite(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias, Tensor kv_cache,
+                  const Tensor& cos_t, const Tensor& sin_t,
+                  const Tensor& tok_pos, const Tensor& tok_seq, const Tensor& block_table,
+                  int64_t Hq, int64_t Hkv, int64_t D, bool use_rope) {
+  rope_kvwrite_impl(qkv, partial, splits, pbias, kv_cache, c10::nullopt, cos_t, sin_t, tok_pos, tok_seq, block_table, Hq, Hkv, D, use_rope);
+}
+
+// The same into the e4m3 cache: quantises K (after RoPE) and V per (token, kv head).
+void rope_kvwrite8(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbias, Tensor kv_cache, Tensor kv_scale,
+                   const Tensor& cos_t, const Tensor& sin_t,
+                   const Tensor& tok_pos, const Tensor& tok_seq, const Tensor& block_table,
+                   int64_t Hq, int64_t Hkv, int64_t D, bool use_rope) {
+  rope_kvwrite_impl(qkv, partial, splits, pbias, kv_cache, kv_scale, cos_t, sin_t, tok_pos, tok_seq, block_table, Hq, Hkv, D, use_rope);
 }
 
 // Kernel for bf16 GEMMs of more than 256 rows: 0 = default (2), 1 = 256 x 256 tiles, 2 = the streaming
@@ -399,16 +428,17 @@ int64_t attention_ws_floats(int64_t B, int64_t max_q_len, int64_t Hq, int64_t Hk
   return dlia_paged_attention_ws_floats((int)B, (int)max_q_len, (int)Hq, (int)Hkv, (int)D, (int)splits);
 }
 
-void paged_attention(Tensor out, const Tensor& qkv, const Tensor& kv_cache, const Tensor& q_start,
-                     const Tensor& ctx_lens, const Tensor& block_table, OptTensor slots, OptTensor partial,
-                     int64_t max_q_len, int64_t Hq, int64_t Hkv, int64_t D, double scale, int64_t splits) {
+static void paged_attention_impl(Tensor out, const Tensor& qkv, const Tensor& kv_cache, OptTensor kv_scale,
+                                 const Tensor& q_start, const Tensor& ctx_lens, const Tensor& block_table,
+                                 OptTensor slots, OptTensor partial, int64_t max_q_len, int64_t Hq, int64_t Hkv,
+                                 int64_t D, double scale, int64_t splits) {
   check_bf16(out, "out"); check_bf16(qkv, "qkv"); check_rows(out, "out"); check_rows(qkv, "qkv");
   DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
   DLIA_CHECK(Hq % Hkv == 0, "Hq must be a multiple of Hkv");
   const int64_t g = Hq / Hkv;
   DLIA_CHECK(g == 1 || g == 2 || g == 4 || g == 8 || g == 16, "GQA group size must be a power of two <= 16");
   DLIA_CHECK(qkv.size(1) >= Hq * D && out.size(1) >= Hq * D, "qkv/out width");
-  auto geo = check_kv(kv_cache, Hkv, D);
+  auto geo = kv_scale.has_value() ? check_kv8(kv_cache, *kv_scale, Hkv, D) : check_kv(kv_cache, Hkv, D);
   check_i32(q_start, "q_start"); check_i32(ctx_lens, "ctx_lens"); check_i32(block_table, "block_table");
   const int64_t B = ctx_lens.numel();
   DLIA_CHECK(q_start.numel() == B + 1 && block_table.dim() == 2, "attention metadata shapes");
@@ -433,10 +463,24 @@ void paged_attention(Tensor out, const Tensor& qkv, const Tensor& kv_cache, cons
   }
   // The caller guarantees: q_start is non-decreasing with q_start[B] <= rows of qkv/out, chunk
   // lengths <= max_q_len, and ctx_lens[b] + q_len[b] <= 32 * block_table.size(1).
-  dlia_paged_attention(out.data_ptr(), qkv.data_ptr(), kv_cache.data_ptr(), q_start.data_ptr<int>(),
+  dlia_paged_attention(out.data_ptr(), qkv.data_ptr(), kv_cache.data_ptr(),
+                       kv_scale.has_value() ? kv_scale->data_ptr<float>() : nullptr, q_start.data_ptr<int>(),
                        ctx_lens.data_ptr<int>(), block_table.data_ptr<int>(), slp, pp, (int)B, (int)max_q_len, (int)Hq,
                        (int)Hkv, (int)D, (int)block_table.size(0), (int)block_table.size(1), (int)geo.num_blocks, qkv.stride(0),
                        out.stride(0), (float)scale, sp, cur_stream());
+}
+
+void paged_attention(Tensor out, const Tensor& qkv, const Tensor& kv_cache, const Tensor& q_start,
+                     const Tensor& ctx_lens, const Tensor& block_table, OptTensor slots, OptTensor partial,
+                     int64_t max_q_len, int64_t Hq, int64_t Hkv, int64_t D, double scale, int64_t splits) {
+  paged_attention_impl(out, qkv, kv_cache, c10::nullopt, q_start, ctx_lens, block_table, slots, partial, max_q_len, Hq, Hkv, D, scale, splits);
+}
+
+// The same over the e4m3 cache.
+void paged_attention8(Tensor out, const Tensor& qkv, const Tensor& kv_cache, const Tensor& kv_scale, const Tensor& q_start,
+                      const Tensor& ctx_lens, const Tensor& block_table, OptTensor slots, OptTensor partial,
+                      int64_t max_q_len, int64_t Hq, int64_t Hkv, int64_t D, double scale, int64_t splits) {
+  paged_attention_impl(out, qkv, kv_cache, kv_scale, q_start, ctx_lens, block_table, slots, partial, max_q_len, Hq, Hkv, D, scale, splits);
 }
 
 void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, const Tensor& top_k,
@@ -477,6 +521,8 @@ TORCH_LIBRARY(dlia, m) {
   m.def("norm(Tensor(a!) out, Tensor(b!) x, Tensor? delta, Tensor? partial, int splits, Tensor? pbias, Tensor w, Tensor? b, Tensor? row_idx, float eps, int mode) -> ()");
   m.def("embed(Tensor(a!) out, Tensor ids, Tensor? pos, Tensor wte, Tensor? wpe) -> ()");
   m.def("rope_kvwrite(Tensor(a!) qkv, Tensor? partial, int splits, Tensor? pbias, Tensor(b!) kv_cache, Tensor cos, Tensor sin, Tensor tok_pos, Tensor tok_seq, Tensor block_table, int Hq, int Hkv, int D, bool use_rope) -> ()");
+  m.def("rope_kvwrite8(Tensor(a!) qkv, Tensor? partial, int splits, Tensor? pbias, Tensor(b!) kv_cache, Tensor(c!) kv_scale, Tensor cos, Tensor sin, Tensor tok_pos, Tensor tok_seq, Tensor block_table, int Hq, int Hkv, int D, bool use_rope) -> ()");
+  m.def("paged_attention8(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor kv_scale, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
   m.def("gemm(Tensor(a!) out, Tensor x, Tensor wp, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
   m.def("gemm_w8(Tensor(a!) out, Tensor x, Tensor wp, Tensor wscale, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
   m.def("gemm_a8w8(Tensor(a!) out, Tensor xq, Tensor xscale, Tensor wp, Tensor wscale, Tensor? bias, Tensor? residual, Tensor? workspace, int N, int epi, int splitk, int ntw) -> ()");
@@ -495,6 +541,8 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
   m.impl("norm", &norm);
   m.impl("embed", &embed);
   m.impl("rope_kvwrite", &rope_kvwrite);
+  m.impl("rope_kvwrite8", &rope_kvwrite8);
+  m.impl("paged_attention8", &paged_attention8);
   m.impl("gemm", &gemm);
   m.impl("gemm_w8", &gemm_w8);
   m.impl("gemm_a8w8", &gemm_a8w8);

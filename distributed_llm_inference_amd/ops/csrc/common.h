@@ -102,4 +102,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return base + i;
 }
 
+// 4 e4m3 bytes of `d` -> the low (hi = false) or high (hi = true) pair as packed bf16
+__device__ __forceinline__ unsigned fp8x2_to_bf16x2(unsigned d, bool hi) {
+  const f32x2 f = hi ? __builtin_amdgcn_cvt_pk_f32_fp8(d, true) : __builtin_amdgcn_cvt_pk_f32_fp8(d, false);
+  const float a = f.x, b = f.y;
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);   // upper halves
+}
+__device__ __forceinline__ u32x4 fp8x8_to_bf16x8(unsigned d0, unsigned d1) {
+  return u32x4{fp8x2_to_bf16x2(d0, false), fp8x2_to_bf16x2(d0, true), fp8x2_to_bf16x2(d1, false),
+               fp8x2_to_bf16x2(d1, true)};
+}
+
 }  // namespace dlia

@@ -17,6 +17,13 @@
 //  16*(j>>2) + 4*quad + (j&3) — the order in which the S^T accumulator of two 16-key tiles
 //  lands in a lane, so P^T feeds the second MFMA without any data movement:
 //      elem_off(kk, d) = (((d>>4)*4 + ((kk&15)>>2))*16 + (d&15))*8 + ((kk>>4)*4 + (kk&3))
+//
+// fp8 cache (kv_dtype fp8): kv[num_blocks][Hkv][2][32 * D] BYTES of OCP e4m3 plus one fp32 scale per
+// (token, kv head, K|V): kv_scale[num_blocks][Hkv][2][32]. Same fragment order at one byte per
+// element, with TWO fragments per 16-byte lane load (as the fp8 weights): the K load (key tile kt,
+// pair t) holds head-dim k-steps 2t and 2t+1 in bytes 0-7 / 8-15, the V load (pair t) head-dim
+// tiles 2t and 2t+1 — a block is 8 wave-loads of 1 KiB instead of 16. The K scale multiplies a row
+// of S^T, the V scale is folded into P^T, so both MFMAs run on the exactly widened e4m3 values.
 #pragma once
 
 namespace dlia {
@@ -33,6 +40,18 @@ __host__ __device__ inline int k_elem_off(int kk, int d, int D) {
 }
 __host__ __device__ inline int v_elem_off(int kk, int d) {
   return (((d >> 4) * 4 + ((kk & 15) >> 2)) * 16 + (d & 15)) * 8 + ((kk >> 4) * 4 + (kk & 3));
+}
+
+__host__ __device__ inline int k8_byte_off(int kk, int d, int D) {
+  const int kt = kk >> 4, s = d >> 5, q = (d >> 3) & 3, l = q * 16 + (kk & 15);
+  return ((kt * (D / 64) + (s >> 1)) * 64 + l) * 16 + (s & 1) * 8 + (d & 7);
+}
+__host__ __device__ inline int v8_byte_off(int kk, int d) {
+  const int dt = d >> 4, l = ((kk & 15) >> 2) * 16 + (d & 15);
+  return ((dt >> 1) * 64 + l) * 16 + (dt & 1) * 8 + ((kk >> 4) * 4 + (kk & 3));
+}
+__host__ __device__ inline long kv_scale_base(long blk, int h, int Hkv, int which) {
+  return ((blk * Hkv + h) * 2 + which) * kBlockTokens;
 }
 
 }  // namespace dlia

@@ -26,7 +26,7 @@ void dlia_embed(void* out, const int* ids, const int* pos, const void* wte, cons
 // The q/k/v values come from `qkv` itself, or (partial != null) from the fp32 split-K partials
 // [splits][T][(Hq+2Hkv)*D] (+ pbias) of the QKV GEMM; the rotated q is written to `qkv` either way.
 void dlia_rope_kvwrite(void* qkv, const float* partial, int splits, const void* pbias, void* kv_cache,
-                       const float* cos_t, const float* sin_t,
+                       float* kv_scale, const float* cos_t, const float* sin_t,
                        const int* tok_pos, const int* tok_seq, const int* block_table,
                        int T, int Hq, int Hkv, int D, int max_blocks, int num_blocks,
                        int rope_len, int use_rope, hipStream_t stream);
@@ -66,13 +66,13 @@ int dlia_gemm_rows_set_narrow(int on);
 
 // ---- attention.hip --------------------------------------------------------------------
 // Causal GQA attention of ragged query chunks against the paged KV cache (prefill chunks and
-// single-token decode are the same kernel). Work items are (sequence, kv head, query tile,
+// single-token decode are the same kernel). kv_scale != null: e4m3 cache + per-(token, head) scales. Work items are (sequence, kv head, query tile,
 // kv split); `partial` holds split-KV partials when splits > 1.
-void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache,
+void dlia_paged_attention(void* out, const void* qkv, const void* kv_cache, const float* kv_scale,
                           const int* q_start, const int* ctx_lens, const int* block_table,
-                          const int* slots, float* partial, int B, int max_q_len, int Hq, int Hkv,
-                          int D, int table_rows, int max_blocks, int num_blocks, long ldq, long ldo,
-                          float scale, int splits, hipStream_t stream);
+                          const int* slots, float* partial, int B, int max_q_len, int Hq,
+                          int Hkv, int D, int table_rows, int max_blocks, int num_blocks,
+                          long ldq, long ldo, float scale, int splits, hipStream_t stream);
 long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits);
 
 // ---- sampler.hip ----------------------------------------------------------------------

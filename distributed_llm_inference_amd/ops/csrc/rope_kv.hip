@@ -5,6 +5,10 @@
 // layer's paged cache at (block_table[seq][pos / 32], pos % 32) in MFMA-fragment order
 // (kv_layout.h). cos/sin come from a table built once per stage.
 //
+// KV8: the cache is OCP e4m3 with one fp32 scale per (token, kv head, K|V) (kv_layout.h). The items
+// of one head are consecutive threads of an aligned lane group (D/16 lanes for K, D/8 for V), so
+// the head's max |x| is a few shuffles; values are quantised from fp32, not from the bf16 rounding.
+//
 // The reference has no KV cache (`use_cache=False`, Worker1.py:134) and recomputes rotary
 // tables for the full sequence on every worker for every token (Worker1.py:93-117).
 #include "common.h"
@@ -55,10 +59,20 @@ struct QkvSrc {
   }
 };
 
-template <bool ROPE>
+// 8 fp32 values / scale -> 8 e4m3 bytes
+__device__ __forceinline__ u32x2 quant8(const float (&f)[8], float inv) {
+  unsigned lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+  return u32x2{lo, hi};
+}
+
+template <bool ROPE, bool KV8>
 __global__ __launch_bounds__(256) void rope_kvwrite_kernel(
     bf16* __restrict__ qkv, const float* __restrict__ partial, int splits, const bf16* __restrict__ pbias, int T,
-    bf16* __restrict__ kv, const float* __restrict__ cos_t,
+    bf16* __restrict__ kv, float* __restrict__ kv_scale, const float* __restrict__ cos_t,
     const float* __restrict__ sin_t, const int* __restrict__ tok_pos, const int* __restrict__ tok_seq,
     const int* __restrict__ block_table, int Hq, int Hkv, int D, int max_blocks, int num_blocks, int rope_len) {
   const int t = blockIdx.x;
@@ -97,14 +111,25 @@ __global__ __launch_bounds__(256) void rope_kvwrite_kernel(
         hi[j] = b * c + a * s;
       }
     }
-    const u32x4 vlo = pack8(lo), vhi = pack8(hi);
     if (!is_k) {
-      st16(p, vlo);
-      st16(p + half, vhi);
+      st16(p, pack8(lo));
+      st16(p + half, pack8(hi));
+    } else if constexpr (KV8) {
+      float am = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) am = fmaxf(am, fmaxf(fabsf(lo[j]), fabsf(hi[j])));
+      for (int x = 1; x < octs; x <<= 1) am = fmaxf(am, __shfl_xor(am, x, 64));   // the head's octs lanes
+      const float sc = fmaxf(am, 1e-12f) * (1.f / 448.f), inv = 1.f / sc;
+      if (kv_ok) {
+        unsigned char* base = reinterpret_cast<unsigned char*>(kv) + kv_head_base(blk, head - Hq, Hkv, D, 0);
+        *reinterpret_cast<u32x2*>(base + k8_byte_off(kk, o * 8, D)) = quant8(lo, inv);
+        *reinterpret_cast<u32x2*>(base + k8_byte_off(kk, half + o * 8, D)) = quant8(hi, inv);
+        if (o == 0) kv_scale[kv_scale_base(blk, head - Hq, Hkv, 0) + kk] = sc;
+      }
     } else if (kv_ok) {
       bf16* base = kv + kv_head_base(blk, head - Hq, Hkv, D, 0);
-      st16(base + k_elem_off(kk, o * 8, D), vlo);
-      st16(base + k_elem_off(kk, half + o * 8, D), vhi);
+      st16(base + k_elem_off(kk, o * 8, D), pack8(lo));
+      st16(base + k_elem_off(kk, half + o * 8, D), pack8(hi));
     }
   }
   if (!kv_ok) return;
@@ -115,20 +140,34 @@ __global__ __launch_bounds__(256) void rope_kvwrite_kernel(
     const int h = it / vocts, o = it - h * vocts;
     float vf[8];
     src.load8((Hq + Hkv) * D + h * D + o * 8, vf);
-    const u32x4 v = pack8(vf);
-    unsigned short* base = kvs + kv_head_base(blk, h, Hkv, D, 1);
+    if constexpr (KV8) {
+      float am = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned w = v[j >> 1];
-      base[v_elem_off(kk, o * 8 + j)] = (unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu));
+      for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(vf[j]));
+      for (int x = 1; x < vocts; x <<= 1) am = fmaxf(am, __shfl_xor(am, x, 64));   // the head's vocts lanes
+      const float sc = fmaxf(am, 1e-12f) * (1.f / 448.f);
+      const u32x2 q = quant8(vf, 1.f / sc);
+      unsigned char* base = reinterpret_cast<unsigned char*>(kv) + kv_head_base(blk, h, Hkv, D, 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) base[v8_byte_off(kk, o * 8 + j)] = (unsigned char)(q[j >> 2] >> ((j & 3) * 8));
+      if (o == 0) kv_scale[kv_scale_base(blk, h, Hkv, 1) + kk] = sc;
+    } else {
+      const u32x4 v = pack8(vf);
+      unsigned short* base = kvs + kv_head_base(blk, h, Hkv, D, 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned w = v[j >> 1];
+        base[v_elem_off(kk, o * 8 + j)] = (unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu));
+      }
     }
   }
 }
 
 }  // namespace dlia
 
+// kv_scale != null: kv_cache is the e4m3 cache (bytes) and kv_scale its [blocks][Hkv][2][32] scales.
 extern "C" void dlia_rope_kvwrite(void* qkv, const float* partial, int splits, const void* pbias, void* kv_cache,
-                                  const float* cos_t, const float* sin_t,
+                                  float* kv_scale, const float* cos_t, const float* sin_t,
                                   const int* tok_pos, const int* tok_seq, const int* block_table,
                                   int T, int Hq, int Hkv, int D, int max_blocks, int num_blocks,
                                   int rope_len, int use_rope, hipStream_t stream) {
@@ -138,12 +177,11 @@ extern "C" void dlia_rope_kvwrite(void* qkv, const float* partial, int splits, c
   const int items = (Hq + Hkv) * (D / 16) + Hkv * (D / 8);
   int gy = 1;
   while (gy < 8 && T * gy < 512 && items > 256 * gy) gy *= 2;
-  if (use_rope)
-    hipLaunchKernelGGL((rope_kvwrite_kernel<true>), dim3(T, gy), dim3(256), 0, stream, (bf16*)qkv, partial, splits,
-                       (const bf16*)pbias, T, (bf16*)kv_cache,
-                       cos_t, sin_t, tok_pos, tok_seq, block_table, Hq, Hkv, D, max_blocks, num_blocks, rope_len);
-  else
-    hipLaunchKernelGGL((rope_kvwrite_kernel<false>), dim3(T, gy), dim3(256), 0, stream, (bf16*)qkv, partial, splits,
-                       (const bf16*)pbias, T, (bf16*)kv_cache,
-                       cos_t, sin_t, tok_pos, tok_seq, block_table, Hq, Hkv, D, max_blocks, num_blocks, rope_len);
+#define DLIA_ROPE(R, Q)                                                                                               \
+  hipLaunchKernelGGL((rope_kvwrite_kernel<R, Q>), dim3(T, gy), dim3(256), 0, stream, (bf16*)qkv, partial, splits,     \
+                     (const bf16*)pbias, T, (bf16*)kv_cache, kv_scale, cos_t, sin_t, tok_pos, tok_seq, block_table,  \
+                     Hq, Hkv, D, max_blocks, num_blocks, rope_len)
+  if (kv_scale) { if (use_rope) DLIA_ROPE(true, true); else DLIA_ROPE(false, true); }
+  else          { if (use_rope) DLIA_ROPE(true, false); else DLIA_ROPE(false, false); }
+#undef DLIA_ROPE
 }

@@ -136,6 +136,30 @@ def kv_block_to_dense(slab_k: torch.Tensor, slab_v: torch.Tensor, D: int):
     return k, v
 
 
+def k8_byte_off(kk, d, D: int):
+    """Byte offset of K[kk][d] inside an e4m3 K slab (csrc/kv_layout.h): two fragments per 16-byte lane load."""
+    kt, s, q = kk >> 4, d >> 5, (d >> 3) & 3
+    lane = q * 16 + (kk & 15)
+    return ((kt * (D // 64) + (s >> 1)) * 64 + lane) * 16 + (s & 1) * 8 + (d & 7)
+
+
+def v8_byte_off(kk, d):
+    dt = d >> 4
+    lane = ((kk & 15) >> 2) * 16 + (d & 15)
+    return ((dt >> 1) * 64 + lane) * 16 + (dt & 1) * 8 + ((kk >> 4) * 4 + (kk & 3))
+
+
+def kv8_block_to_dense(slab_k: torch.Tensor, slab_v: torch.Tensor, scale_k: torch.Tensor, scale_v: torch.Tensor, D: int):
+    """e4m3 slabs [..., 32*D] (uint8) + scales [..., 32] -> dequantised fp32 ([..., 32, D], [..., 32, D])."""
+    kk = torch.arange(KV_BLOCK, device=slab_k.device).view(-1, 1)
+    d = torch.arange(D, device=slab_k.device).view(1, -1)
+    ko = k8_byte_off(kk, d, D).reshape(-1)
+    vo = v8_byte_off(kk, d).reshape(-1)
+    k = slab_k[..., ko].reshape(*slab_k.shape[:-1], KV_BLOCK, D).view(torch.float8_e4m3fn).float()
+    v = slab_v[..., vo].reshape(*slab_v.shape[:-1], KV_BLOCK, D).view(torch.float8_e4m3fn).float()
+    return k * scale_k[..., None], v * scale_v[..., None]
+
+
 def dense_to_kv_block(k: torch.Tensor, v: torch.Tensor):
     """Inverse of kv_block_to_dense: [..., 32, D] -> [..., 32*D] slabs."""
     D = k.shape[-1]

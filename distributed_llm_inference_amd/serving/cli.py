@@ -21,6 +21,7 @@ def _add_engine_args(ap):
     ap.add_argument("--config", help="YAML file with EngineConfig fields")
     ap.add_argument("--model")
     ap.add_argument("--dtype", choices=["bf16", "fp8", "fp8w", "fp32"], help="fp8 = layer GEMMs on the fp8 MFMA; fp8w = e4m3 weights only")
+    ap.add_argument("--kv-dtype", choices=["bf16", "fp8"], help="fp8 = e4m3 KV cache with one scale per token and kv head (HIP backend)")
     ap.add_argument("--pp-size", type=int)
     ap.add_argument("--partition", choices=["balanced", "even", "explicit"])
     ap.add_argument("--layer-ranges", help='explicit ranges, e.g. "0-11,11-22"')
@@ -47,7 +48,7 @@ def _add_engine_args(ap):
 def config_from_args(a) -> EngineConfig:
     base = EngineConfig.from_yaml(a.config).to_dict() if getattr(a, "config", None) else {}
     base = EngineConfig.from_env(EngineConfig.from_dict(base)).to_dict()
-    for k in ("model", "dtype", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
+    for k in ("model", "dtype", "kv_dtype", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
               "max_seq_len", "prefill_chunk", "kv_blocks", "max_tokens_cap", "host", "port", "seed", "fault_inject",
               "trace_path"):
         v = getattr(a, k, None)

@@ -78,7 +78,8 @@ def test_micro_batch_shrinks_when_the_kv_cache_would_not_fit(monkeypatch):
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(total_memory=288 * 2 ** 30))
 
     def fit(steps, world):
-        a = types.SimpleNamespace(model="llama-3-8b", partition="balanced", batch=1024, prompt_len=128, steps=steps, warmup=4)
+        a = types.SimpleNamespace(model="llama-3-8b", partition="balanced", batch=1024, prompt_len=128, steps=steps, warmup=4,
+                                  kv_dtype="bf16")
         max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
         return b._fit_batch(a, 2 * world, max_seq, world)
 

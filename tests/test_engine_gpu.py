@@ -169,3 +169,16 @@ def test_two_stage_processes_on_one_gpu_over_host_staged_gloo():
     finally:
         pipe.close()
     assert got == ref
+
+
+def test_fp8_kv_cache_through_the_engine():
+    """kv_dtype fp8 on the full serving path (continuous batching, hipGraph decode, 2 stages): every
+    request completes, and greedy tokens mostly agree with the bf16-cache run (quantisation noise may
+    flip a near-tie, after which a sequence diverges)."""
+    ps = prompts(8, seed=6)
+    ref, _ = run(cfg(), ps, greedy(16))
+    got, snap = run(cfg(pp_size=2, num_micro_batches=3, kv_dtype="fp8"), ps, greedy(16))
+    assert snap["fatal"] is None and all(len(o) == 16 for o in got)
+    first = sum(a[0] == b[0] for a, b in zip(ref, got))
+    same = sum(x == y for a, b in zip(ref, got) for x, y in zip(a, b))
+    assert first >= len(ps) - 1 and same >= 0.6 * 16 * len(ps), (first, same)

@@ -391,7 +391,7 @@ def test_gemm_large_m_column_blocks_not_a_multiple_of_256(K, large_kernel):
 
 
 # ------------------------------------------------------------------------------------------
-def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, qkv_partials=0):
+def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, qkv_partials=0, kv8=False):
     torch.manual_seed(seed)
     B = len(ctx_lens)
     T = sum(q_lens)
@@ -401,7 +401,20 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, q
     num_blocks = B * max_blocks + 3
     perm = torch.randperm(num_blocks)[:B * max_blocks].reshape(B, max_blocks)
     block_table = perm.to(device=DEV, dtype=torch.int32)
-    kv = torch.zeros(num_blocks, Hkv, 2, 32 * D, device=DEV, dtype=torch.bfloat16)
+    kv = torch.zeros(num_blocks, Hkv, 2, 32 * D, device=DEV, dtype=torch.uint8 if kv8 else torch.bfloat16)
+    kvs = torch.zeros(num_blocks, Hkv, 2, 32, device=DEV) if kv8 else None
+
+    def kvwrite(rows, part, S, pb, tp, ts):
+        if kv8:
+            K.rope_kvwrite8(rows, part, S, pb, kv, kvs, cos, sin, tp, ts, block_table, Hq, Hkv, D, use_rope)
+        else:
+            K.rope_kvwrite(rows, part, S, pb, kv, cos, sin, tp, ts, block_table, Hq, Hkv, D, use_rope)
+
+    def qdq(x):
+        """What the e4m3 cache holds of [n, Hkv, D] values: per (token, head) quantise + dequantise."""
+        q, sc = packing.quantize_fp8(x.float().reshape(-1, D))
+        return packing.dequantize_fp8(q, sc).reshape(x.shape)
+
     P = max_len + 8
     inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float64) / D))
     ang = torch.outer(torch.arange(P, dtype=torch.float64), inv)
@@ -420,8 +433,8 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, q
             r[:, (Hq + Hkv) * D:] = hist_v[b].reshape(c, -1)
             rows.append(r); tpos += list(range(c)); tseq += [b] * c
         hq = torch.cat(rows)
-        K.rope_kvwrite(hq, None, 1, None, kv, cos, sin, torch.tensor(tpos, device=DEV, dtype=torch.int32),
-                       torch.tensor(tseq, device=DEV, dtype=torch.int32), block_table, Hq, Hkv, D, use_rope)
+        kvwrite(hq, None, 1, None, torch.tensor(tpos, device=DEV, dtype=torch.int32),
+                torch.tensor(tseq, device=DEV, dtype=torch.int32))
     # the new chunk
     qkv = bf(torch.randn(T, qkv_w, device=DEV))
     qkv0 = qkv.clone()
@@ -436,11 +449,9 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, q
         parts = torch.randn(S, T, qkv_w, device=DEV)
         parts[0] = qkv0.float() - pb.float() - parts[1:].sum(0)
         qkv.fill_(float("nan"))
-        K.rope_kvwrite(qkv, parts.contiguous(), S, pb, kv, cos, sin, tpos_t,
-                       torch.tensor(tseq, device=DEV, dtype=torch.int32), block_table, Hq, Hkv, D, use_rope)
+        kvwrite(qkv, parts.contiguous(), S, pb, tpos_t, torch.tensor(tseq, device=DEV, dtype=torch.int32))
     else:
-        K.rope_kvwrite(qkv, None, 1, None, kv, cos, sin, tpos_t, torch.tensor(tseq, device=DEV, dtype=torch.int32),
-                       block_table, Hq, Hkv, D, use_rope)
+        kvwrite(qkv, None, 1, None, tpos_t, torch.tensor(tseq, device=DEV, dtype=torch.int32))
     out = torch.full((T, Hq * D), float("nan"), device=DEV, dtype=torch.bfloat16)
     q_start_t = torch.tensor(q_start, device=DEV, dtype=torch.int32)
     ctx_t = torch.tensor(ctx_lens, device=DEV, dtype=torch.int32)
@@ -450,7 +461,10 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, q
         n = K.attention_ws_floats(B, max_q, Hq, Hkv, D, splits)
         partial = torch.full((n,), float("nan"), device=DEV, dtype=torch.float32)
     scale = 1.0 / math.sqrt(D)
-    K.paged_attention(out, qkv, kv, q_start_t, ctx_t, block_table, None, partial, max_q, Hq, Hkv, D, scale, splits)
+    if kv8:
+        K.paged_attention8(out, qkv, kv, kvs, q_start_t, ctx_t, block_table, None, partial, max_q, Hq, Hkv, D, scale, splits)
+    else:
+        K.paged_attention(out, qkv, kv, q_start_t, ctx_t, block_table, None, partial, max_q, Hq, Hkv, D, scale, splits)
     torch.cuda.synchronize()
 
     # reference
@@ -469,6 +483,25 @@ def _attn_case(K, Hq, Hkv, D, ctx_lens, q_lens, splits, seed=0, use_rope=True, q
             qr, kr = qn, k_all
         # rotated q must have been written back in place
         assert_close(qkv[sl, :Hq * D].reshape(q, Hq, D), qr, 2e-2, 2e-2, "rope(q) in place")
+        if kv8:
+            # the cache quantises the fp32 rotation result (not its bf16 rounding) and V as given
+            k_c = qdq(ref.rope(k_all, cos, sin, pos_all) if use_rope else k_all)
+            v_c = qdq(v_all)
+            want = ref.attention(qr, k_c, v_c, c, scale).reshape(q, Hq * D)
+            assert_close(out[sl], want, 3e-2, 3e-2, f"attention over the e4m3 cache b={b} ctx={c} q={q} splits={splits}")
+            nb = (c + q + 31) // 32
+            idx = block_table[b, :nb].long()
+            kd, vd = packing.kv8_block_to_dense(kv[idx][:, :, 0], kv[idx][:, :, 1], kvs[idx][:, :, 0], kvs[idx][:, :, 1], D)
+            kd = kd.permute(0, 2, 1, 3).reshape(nb * 32, Hkv, D)[:c + q]
+            vd = vd.permute(0, 2, 1, 3).reshape(nb * 32, Hkv, D)[:c + q]
+            # a value on an e4m3 rounding boundary may land one step away (the two sides round the scale /
+            # the rotation differently in the last bit): all within one step, nearly all identical
+            for name, got, ref_c in (("K", kd, k_c), ("V", vd, v_c)):
+                err = (got - ref_c).abs()
+                step = ref_c.abs() * 0.126 + ref_c.abs().amax(dim=-1, keepdim=True) * 2.3e-3
+                assert bool((err <= step).all()), f"{name} cache: max err {err.max().item()}"
+                assert (err > 1e-6 + 1e-3 * ref_c.abs()).float().mean().item() < 0.01, f"{name} cache: too many off-by-one-step values"
+            continue
         want = ref.attention(qr, kr, v_all, c, scale).reshape(q, Hq * D)
         assert_close(out[sl], want, 2e-2, 2e-2, f"attention b={b} ctx={c} q={q} Hq={Hq} Hkv={Hkv} D={D} splits={splits}")
         # cache content round-trips through the fragment layout
@@ -504,6 +537,21 @@ def test_attention_prefill_ragged(K, geom):
 
 def test_attention_prefill_chunk_splitkv_norope(K):
     _attn_case(K, 12, 12, 64, ctx_lens=[130, 0], q_lens=[20, 50], splits=2, use_rope=False)
+
+
+@pytest.mark.parametrize("geom", [(32, 8, 128), (32, 4, 64), (12, 12, 64), (64, 8, 128)])
+def test_attention_fp8_kv_cache_decode(K, geom):
+    """e4m3 KV cache with per-(token, head) scales: write kernel + attention against the fp32 reference
+    over the dequantised cache contents."""
+    Hq, Hkv, D = geom
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 1, 31, 32, 100, 257], q_lens=[1] * 6, splits=1, kv8=True)
+
+
+def test_attention_fp8_kv_cache_prefill_splitkv_and_partials(K):
+    _attn_case(K, 32, 8, 128, ctx_lens=[0, 0, 40, 96], q_lens=[77, 5, 33, 64], splits=1, kv8=True)
+    _attn_case(K, 32, 8, 128, ctx_lens=[5, 700, 64, 333], q_lens=[1] * 4, splits=4, kv8=True)
+    _attn_case(K, 12, 12, 64, ctx_lens=[130, 0], q_lens=[20, 50], splits=2, use_rope=False, kv8=True)
+    _attn_case(K, 32, 8, 128, ctx_lens=[3, 64], q_lens=[1, 1], splits=1, qkv_partials=4, kv8=True)
 
 
 @pytest.mark.parametrize("use_rope", [True, False])

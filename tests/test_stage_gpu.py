@@ -155,3 +155,38 @@ def test_fp8_weight_stage_tracks_bf16_stage(mode):
         la, lb = a.forward(d, torch.tensor(t)).clone(), b.forward(d, torch.tensor(t)).clone()
         near(lb, la, f"fp8 decode logits step {i}")
         ctx = [c + 1 for c in ctx]
+
+
+def test_fp8_kv_cache_stage_tracks_bf16_cache_stage():
+    """kv_dtype fp8 (e4m3 K/V with one scale per token and kv head): half the cache bytes per token and
+    logits close to the bf16-cache stage through prefill, eager decode and hipGraph decode."""
+    from distributed_llm_inference_amd.models.stage_gpu import GpuStage
+    spec = gpu_spec("llama")
+    plan = make_plans(spec, 1)[0]
+    mk = lambda kd: GpuStage(spec, plan, random_stage_weights(spec, plan, seed=5, dtype=torch.bfloat16), max_slots=8,
+                             max_seq_len=256, num_blocks=64, max_tokens=320, max_batch=8, kv_dtype=kd)
+    a, b = mk("bf16"), mk("fp8")
+    ra, rb = a.memory_report(), b.memory_report()
+    assert ra["kv_blocks"] == rb["kv_blocks"] and rb["kv_gib"] < 0.55 * ra["kv_gib"]
+    g = torch.Generator().manual_seed(0)
+    lens = [230, 70]
+    toks = torch.randint(3, spec.vocab_size, (sum(lens),), generator=g).tolist()
+    tables = {0: list(range(0, 8)), 1: list(range(8, 16))}
+    d = step([0, 1], lens, [0, 0], toks, tables=tables)
+
+    def near(x, y, what):
+        x, y = x.float().cpu(), y.float().cpu()
+        err, scale = (x - y).abs().max().item(), y.abs().max().item()
+        assert err <= 0.1 * scale, f"{what}: max err {err:.4f} vs scale {scale:.4f}"
+        cos = torch.nn.functional.cosine_similarity(x.flatten(), y.flatten(), dim=0).item()
+        assert cos > 0.99, f"{what}: cosine {cos:.4f}"
+
+    la, lb = a.forward(d, torch.tensor(toks)).clone(), b.forward(d, torch.tensor(toks)).clone()
+    near(lb, la, "fp8-KV prefill logits")
+    ctx = list(lens)
+    for i in range(3):                                   # eager decode over the quantised history
+        t = [int(x) for x in la.argmax(-1).tolist()]
+        d = step([0, 1], [1, 1], ctx, t)
+        la, lb = a.forward(d, torch.tensor(t)).clone(), b.forward(d, torch.tensor(t)).clone()
+        near(lb, la, f"fp8-KV decode logits step {i}")
+        ctx = [c + 1 for c in ctx]
