@@ -29,10 +29,11 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=2)
     ap.add_argument("--pp-size", type=int, default=1)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"])
     ap.add_argument("--cpu", action="store_true")
     a = ap.parse_args()
     cfg = EngineConfig(model=a.model, pp_size=a.pp_size, max_batch=a.batch, num_micro_batches=a.micro_batches,
-                       max_seq_len=((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=2048, dtype=a.dtype,
+                       max_seq_len=((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=2048, dtype=a.dtype, kv_dtype=a.kv_dtype,
                        device="cpu" if a.cpu else "auto", backend="torch" if a.cpu else "auto",
                        transport="loopback" if a.cpu else "auto")
     pipe = make_pipeline(cfg)
@@ -63,7 +64,7 @@ def main():
                       "output_tok_per_s": round(out_tokens / dt, 1), "requests_per_s": round(a.requests / dt, 2),
                       "ttft_ms_p50": q(ttft, 0.5), "ttft_ms_p99": q(ttft, 0.99), "tpot_ms_p50": q(tpot, 0.5),
                       "tpot_ms_p99": q(tpot, 0.99), "recompositions": snap.get("recompositions"),
-                      "config": {"max_batch": a.batch, "micro_batches": a.micro_batches, "pp": a.pp_size, "dtype": a.dtype}}))
+                      "config": {"max_batch": a.batch, "micro_batches": a.micro_batches, "pp": a.pp_size, "dtype": a.dtype, "kv_dtype": a.kv_dtype}}))
 
 
 if __name__ == "__main__":
