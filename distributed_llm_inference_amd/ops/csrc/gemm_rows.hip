@@ -102,8 +102,10 @@ __device__ __forceinline__ const void* r2_sel(bool c, const void* a, const void*
 // (~70 cycles a piece). A schedule that lets compute waves prefetch the next chunk before the
 // barrier — loaders guaranteeing chunk c+1 instead of c at barrier c — was tried and ran at 0.88
 // instead of 1.15 PFLOP/s at 4096 rows: it costs one chunk of prefetch distance, and a piece takes
-// longer than one chunk to land. Hiding those reads needs finer stages (32 K-elements, a deeper
-// ring) so that the distance can be kept; LDS has no room for a fourth 32 KiB x stage.
+// longer than one chunk to land; LDS has no room for a fourth 32 KiB x stage. What the bf16 kernel
+// does instead is hold back the last MFMA group of a chunk and execute it right after the next
+// barrier, under the new chunk's first reads (HOLD below): 1.13-1.15 -> 1.17 PFLOP/s at 4096 rows —
+// the SIMD partner wave was already covering most of that gap.
 template <int ROWS, bool F8, bool DIAG = false>
 __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) {
   using C = RowsCfg<ROWS>;
@@ -215,6 +217,14 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     const int xoff = (mh * (ROWS / 2) + l15) * 128;
     const int sw = (l15 >> 1) & 7;
     long d_bar = 0, d_rd = 0, d_mfma = 0;
+    constexpr bool HOLD = !F8 && !DIAG && G >= 2 && (G % 2) == 0;   // see the HOLD branch below
+    u32x4 hwf[2][2], hxg[2][GS];                              // HOLD: fragments carried across chunks
+    if constexpr (HOLD) {                                     // chunk 0 has nothing held: zero operands add zero
+#pragma unroll
+      for (int j = 0; j < 2; ++j) hwf[1][j] = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int i4 = 0; i4 < GS; ++i4) hxg[1][i4] = u32x4{0, 0, 0, 0};
+    }
     for (int c = 0; c < n; ++c) {
       long t0 = 0, t1 = 0, t2 = 0;
       if constexpr (DIAG) t0 = __builtin_amdgcn_s_memtime();
@@ -228,7 +238,47 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
       auto xfrag = [&](int i, int kk) -> u32x4 {
         return *reinterpret_cast<const u32x4*>(xb + i * 2048 + (((kk * 4 + quad) ^ sw) << 4));
       };
-      if constexpr (F8) {
+      if constexpr (HOLD) {
+        // Held-back last group: right after the barrier the matrix core would idle ~240 cycles until
+        // the first fragment reads of the chunk return (stamps above). The last MFMA group of chunk
+        // c-1 — k-step 1, m-tile group GPK-1, whose operands hw = wf[1] and hx = xg[1] were read from
+        // chunk c-1's stage BEFORE this barrier and are complete (lgkmcnt(0) below) — is executed
+        // here instead, under the new reads. Buffer roles repeat every chunk (G is even), so nothing
+        // is copied: new wf[0] / xg[0] load first, the held MFMAs consume old wf[1] / xg[1], then
+        // new wf[1] loads (needed from group GPK on) and group 1 prefetches into xg[1].
+#pragma unroll
+        for (int j = 0; j < 2; ++j) hwf[0][j] = *reinterpret_cast<const u32x4*>(wb + (j * 2) * 1024);
+#pragma unroll
+        for (int i4 = 0; i4 < GS; ++i4) hxg[0][i4] = xfrag(i4, 0);
+        __builtin_amdgcn_sched_barrier(0);                    // the reads go out BEFORE the held MFMAs, not after
+#pragma unroll
+        for (int i4 = 0; i4 < GS; ++i4)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[(GPK - 1) * GS + i4][j] = mfma16(hwf[1][j], hxg[1][i4], acc[(GPK - 1) * GS + i4][j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) hwf[1][j] = *reinterpret_cast<const u32x4*>(wb + (j * 2 + 1) * 1024);
+#pragma unroll
+        for (int g = 0; g + 1 < G; ++g) {
+          const int kk = g / GPK, ig = g % GPK;
+#pragma unroll
+          for (int i4 = 0; i4 < GS; ++i4) hxg[(g + 1) & 1][i4] = xfrag(((g + 1) % GPK) * GS + i4, (g + 1) / GPK);
+#pragma unroll
+          for (int i4 = 0; i4 < GS; ++i4)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[ig * GS + i4][j] = mfma16(hwf[kk][j], hxg[g & 1][i4], acc[ig * GS + i4][j]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // group G-1 stays in hwf[1] / hxg[1]; its reads must be complete before the next barrier lets
+        // the loaders overwrite this chunk's stage
+        // (the builtin, not inline asm: hipcc's own wait insertion then knows the held fragments are
+        // complete and does not drain the NEW reads before the held MFMAs of the next chunk;
+        // 0xC07F = lgkmcnt(0) with vmcnt / expcnt left at "no wait")
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (F8) {
         // one MX MFMA per (m-tile, n-tile) and chunk; fragments are 32 bytes per lane
         i32x8 wf8[2], xq[2][GS];
         auto xfrag8 = [&](int i) -> i32x8 {
@@ -290,6 +340,13 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
         d_bar += t1 - t0; d_rd += t2 - t1; d_mfma += t3 - t2;
       }
       }
+    }
+    if constexpr (HOLD) {                                     // the last chunk's held group
+#pragma unroll
+      for (int i4 = 0; i4 < GS; ++i4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[(GPK - 1) * GS + i4][j] = mfma16(hwf[1][j], hxg[1][i4], acc[(GPK - 1) * GS + i4][j]);
     }
     if constexpr (DIAG) {
       if (lane == 0) {
