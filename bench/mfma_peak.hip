@@ -52,6 +52,45 @@ __global__ __launch_bounds__(512) void mfma_loop(float* out, long* clocks, int i
   }
 }
 
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// the same loop on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales): 4x the
+// multiply-adds per instruction at twice the rate
+__global__ __launch_bounds__(512) void mfma8_loop(float* out, long* clocks, int iters, unsigned seed) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  i32x8 a[4], b[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 8; ++j) {
+      unsigned h = (t * 2654435761u + (i * 8 + j) * 40503u + seed) * 2246822519u;
+      // four e4m3 bytes, exponent field <= 13 of 15 (no NaN encodings), random sign and mantissa
+      unsigned v = 0;
+      for (int k = 0; k < 4; ++k) { h = h * 3266489917u + 1u; v |= (((h >> 8) & 0x87u) | ((((h >> 16) % 13u) + 1u) << 3)) << (8 * k); }
+      a[i][j] = seed ? (int)v : 0;
+      b[i][j] = seed ? (int)((v >> 8) | (v << 24)) : 0;
+    }
+  f32x4 acc[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+  const long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  out[t] = s;
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned w = t >> 6;
+    clocks[2 * w] = c1 - c0;
+    clocks[2 * w + 1] = r1 - r0;
+  }
+}
+
 int main() {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { printf("no device\n"); return 1; }
@@ -62,11 +101,13 @@ int main() {
   hipMalloc(&clocks, waves * 16);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int pass = 0; pass < 2; ++pass) {
-    const unsigned seed = pass == 0 ? 12345u : 0u;
+  for (int pass = 0; pass < 4; ++pass) {
+    const unsigned seed = (pass & 1) == 0 ? 12345u : 0u;
+    const bool f8 = pass >= 2;
     for (int rep = 0; rep < 3; ++rep) {                                    // the last repetition is reported
       hipEventRecord(e0);
-      hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(threads), 0, 0, out, clocks, iters, seed);
+      if (f8) hipLaunchKernelGGL(mfma8_loop, dim3(blocks), dim3(threads), 0, 0, out, clocks, iters / 2, seed);
+      else    hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(threads), 0, 0, out, clocks, iters, seed);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
     }
@@ -77,10 +118,11 @@ int main() {
     double ghz = 0;
     for (long w = 0; w < waves; ++w) ghz += (double)h[2 * w] / (double)h[2 * w + 1] * 0.1;
     ghz /= waves;
-    const double flop = (double)waves * iters * 16 * 2.0 * 16 * 16 * 32;
-    printf("%s operands: %d CUs x 8 waves, %.2f ms, %.0f TFLOP/s, in-kernel clock %.2f GHz (%.1f cycles per MFMA and SIMD)\n",
-           seed ? "random" : "zero  ", cus, ms, flop / (ms * 1e-3) / 1e12, ghz,
-           ghz * 1e9 * ms * 1e-3 / ((double)iters * 16 * 2));
+    const int n = f8 ? iters / 2 : iters;
+    const double flop = (double)waves * n * 16 * 2.0 * 16 * 16 * (f8 ? 128 : 32);
+    printf("%s %s operands: %d CUs x 8 waves, %.2f ms, %.0f TFLOP/s, in-kernel clock %.2f GHz (%.1f cycles per MFMA and SIMD)\n",
+           f8 ? "e4m3 16x16x128" : "bf16 16x16x32 ", seed ? "random" : "zero  ", cus, ms, flop / (ms * 1e-3) / 1e12, ghz,
+           ghz * 1e9 * ms * 1e-3 / ((double)n * 16 * 2));
   }
   return 0;
 }
