@@ -78,6 +78,8 @@ def build_executor(cfg: EngineConfig, spec: ModelSpec, plan: StagePlan, device: 
                         max_tokens=cfg.prefill_chunk, max_batch=cfg.max_batch, use_graphs=cfg.use_graphs,
                         kv_mem_fraction=cfg.kv_mem_fraction, weight_dtype=cfg.dtype if cfg.dtype in ("fp8", "fp8w") else "bf16",
                         kv_dtype=cfg.kv_dtype)
+    if cfg.kv_dtype != "bf16":
+        raise ValueError(f"kv_dtype {cfg.kv_dtype!r} needs the hip backend (the torch executor keeps its cache in the compute dtype)")
     from ..models.stage_ref import RefStage
     dt = torch.float32 if cfg.dtype in ("fp32", "bf16") and dev == "cpu" else torch.bfloat16
     w = load_weights(cfg, spec, plan, "cpu", torch.float32)

@@ -127,6 +127,16 @@ def test_config_yaml_env_and_validation(tmp_path, monkeypatch):
         EngineConfig(pp_size=0)
     assert EngineConfig(pp_size=1).resolved_transport() == "loopback"
     assert EngineConfig(pp_size=2, device="cpu").resolved_transport() == "gloo"
+    # KV cache dtype: validated, settable from the environment, and refused by the torch executor
+    assert EngineConfig().kv_dtype == "bf16" and EngineConfig(kv_dtype="fp8").to_dict()["kv_dtype"] == "fp8"
+    with pytest.raises(ValueError):
+        EngineConfig(kv_dtype="int4")
+    monkeypatch.setenv("DLIA_KV_DTYPE", "fp8")
+    assert EngineConfig.from_env(EngineConfig()).kv_dtype == "fp8"
+    monkeypatch.delenv("DLIA_KV_DTYPE")
+    from distributed_llm_inference_amd.parallel.launcher import LocalPipeline
+    with pytest.raises(ValueError, match="hip backend"):
+        LocalPipeline(EngineConfig(model="tiny-llama-test", device="cpu", backend="torch", transport="loopback", kv_dtype="fp8"))
 
 
 # ---- model specs / partitioner ---------------------------------------------------------------
