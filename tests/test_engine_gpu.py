@@ -182,3 +182,37 @@ def test_fp8_kv_cache_through_the_engine():
     first = sum(a[0] == b[0] for a, b in zip(ref, got))
     same = sum(x == y for a, b in zip(ref, got) for x, y in zip(a, b))
     assert first >= len(ps) - 1 and same >= 0.6 * 16 * len(ps), (first, same)
+
+
+@pytest.mark.parametrize("kv_dtype", ["bf16", "fp8"])
+def test_stale_cache_contents_never_influence_results(kv_dtype):
+    """Blocks are recycled without being cleared, and a block's tail beyond the sequence was never
+    written: whatever bytes (and, for the e4m3 cache, scales) sit there must not matter. Serving on
+    a cache pre-filled with random finite garbage gives exactly the tokens of a zeroed cache, with
+    more requests than slots so blocks are handed on between sequences."""
+    ps = prompts(20, seed=9)
+    c = cfg(kv_dtype=kv_dtype, max_batch=4, num_micro_batches=2)
+
+    def serve(poison):
+        pipe = LocalPipeline(c)
+        try:
+            ex = pipe.executors[0]
+            if poison:
+                g = torch.Generator(device="cuda").manual_seed(1)
+                if kv_dtype == "fp8":
+                    b = torch.randint(0, 127, ex.kv.shape, device="cuda", generator=g, dtype=torch.int16)     # no NaN encodings
+                    b |= torch.randint(0, 2, ex.kv.shape, device="cuda", generator=g, dtype=torch.int16) << 7
+                    ex.kv.copy_(b.to(torch.uint8))
+                    ex.kv_scale.copy_(torch.rand(ex.kv_scale.shape, device="cuda", generator=g) * 8 + 0.01)
+                else:
+                    ex.kv.copy_((torch.randn(ex.kv.shape, device="cuda", generator=g) * 30).to(torch.bfloat16))
+            reqs = [pipe.engine.submit(p, greedy(12)) for p in ps]
+            outs = [r.wait(120).output for r in reqs]
+            assert pipe.engine.snapshot()["fatal"] is None
+            return outs
+        finally:
+            pipe.close()
+
+    clean, dirty = serve(False), serve(True)
+    assert all(len(o) == 12 for o in clean)
+    assert dirty == clean
