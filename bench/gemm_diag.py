@@ -29,16 +29,18 @@ def main():
     n_out = a.n // 2 if a.epi == 4 else a.n
     out = torch.empty(a.m, n_out, device="cuda", dtype=torch.bfloat16)
     wgs = ((a.n + 127) // 128 + 7) // 8 * 8 * ((a.m + 255) // 256)
-    dbg = torch.zeros(wgs * 12 * 8, device="cuda", dtype=torch.float32)
+    dbg = torch.zeros(wgs * 12 * 16, device="cuda", dtype=torch.float32)
     for _ in range(3):
         K.gemm(out, x, wp, None, None, dbg, a.n, a.epi, 1, 0)
     torch.cuda.synchronize()
-    d = dbg.view(torch.int64).view(wgs, 12, 4).cpu().double()
+    d = dbg.view(torch.int64).view(wgs, 12, 8).cpu().double()
     d = d[d[:, 0, 3] > 0]                          # workgroups that ran (the grid is padded)
     chunks = d[:, :, 3:4]
     per = d[:, :, :3] / chunks                     # cycles per chunk
     comp, load = per[:, :8].reshape(-1, 3), per[:, 8:].reshape(-1, 3)
     print(f"M={a.m} N={a.n} K={a.k}: {d.shape[0]} workgroups, {int(chunks.max())} chunks each; shader cycles per chunk, median (p90)")
+    ghz = (d[:, :8, 4] / d[:, :8, 5].clamp_min(1)).reshape(-1) * 0.1
+    print(f"  in-kernel clock over the chunk loop: median {ghz.median():.2f} GHz (p10 {ghz.quantile(0.1):.2f}, p90 {ghz.quantile(0.9):.2f})")
     for name, t, cols in (("compute wave", comp, ("barrier wait", "first fragment reads", "MFMA section (32 MFMAs + reads)")),
                           ("loader wave", load, ("vmcnt wait (data landing)", "barrier wait", "DMA issue (12 pieces)"))):
         tot = t.sum(1)

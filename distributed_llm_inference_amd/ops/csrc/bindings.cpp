@@ -314,7 +314,7 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
       if (workspace.has_value()) {
         check_f32(*workspace, "workspace");
         const int64_t wgs = ((N + 127) / 128 + 7) / 8 * 8 * ((M + 255) / 256);
-        DLIA_CHECK(workspace->is_contiguous() && workspace->numel() >= wgs * 12 * 8, "debug buffer too small");
+        DLIA_CHECK(workspace->is_contiguous() && workspace->numel() >= wgs * 12 * 16, "debug buffer too small");
         dbg = workspace->data_ptr<float>();
       }
       dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, dbg, nullptr, (int)M, (int)N, (int)K,

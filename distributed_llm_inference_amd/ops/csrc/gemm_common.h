@@ -20,6 +20,7 @@ struct GemmParams {
   int act;                    // 0 none, 1 swiglu (gate tile, up tile interleaved), 2 gelu_tanh
   int out_f32;
   int partial_only;           // write fp32 partials even when splitk == 1 (a consumer kernel sums them)
+  int group_n;                // gemm_rows.hip only: column blocks per workgroup-order group (set by its launcher)
 };
 
 __device__ __forceinline__ void store4(void* out, long ldo, int m, int n, const float (&v)[4], int out_f32) {

@@ -91,9 +91,10 @@ __device__ __forceinline__ const void* r2_sel(bool c, const void* a, const void*
 //
 // DIAG: diagnostic build (DLIA_GEMM_ROWS_DIAG=1, never used for serving). Every wave accumulates
 // s_memtime deltas of the sections of a chunk and lane 0 stores them to p.partial, which then is a
-// debug buffer [workgroup][12 waves][4] of int64 that no other code reads: compute waves
-// {barrier wait, first fragment reads, MFMA section, chunks}, loaders {vmcnt wait, barrier wait,
-// DMA issue, chunks}. The stamps cost ~10 % themselves; ratios are what they are for.
+// debug buffer [workgroup][12 waves][8] of int64 that no other code reads: compute waves
+// {barrier wait, first fragment reads, MFMA section, chunks, shader cycles and 100 MHz real-time
+// ticks of the whole chunk loop (their ratio is the in-kernel clock)}, loaders {vmcnt wait, barrier
+// wait, DMA issue, chunks}. The stamps cost ~10 % themselves; ratios are what they are for.
 //
 // What the stamps say (256 x 128 tile, gate/up shape, 256 and 4096 rows alike): a chunk takes
 // ~1400 shader cycles for 1024 cycles of MFMA work per SIMD. Compute waves: ~190 at the barrier,
@@ -115,11 +116,19 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, quad = lane >> 4;
   // More rows than ROWS: the grid also walks ROWS-row blocks. Workgroup ids go round-robin over the
-  // 8 XCDs, so the row blocks of one column block get ids that differ by multiples of 8: they run
-  // on the same XCD at about the same time and share each weight byte through its L2.
+  // 8 XCDs; an XCD runs 32 workgroups at a time, in step along K, and what they share they fetch
+  // from beyond its 4 MiB L2 only once. Those 32 are made a patch of (32 / group_n) row blocks x
+  // group_n column blocks (grouped order: within a group of group_n column blocks, ids walk the
+  // columns first, then the rows): with 16 row blocks, group_n = 1 would stream all of x past L2
+  // for every column block, group_n = 4 shares each x line four ways and each weight line eight.
   const int mblocks = (p.M + ROWS - 1) / ROWS;
-  const int within = blockIdx.x >> 3;
-  const int nblk = (within / mblocks) * 8 + (blockIdx.x & 7), mrow0 = (within % mblocks) * ROWS;
+  const int within = blockIdx.x >> 3;                       // index among this XCD's workgroups
+  const int ncb = gridDim.x / (8 * mblocks);                // column blocks per XCD (grid padded to 8)
+  const int grp = within / (p.group_n * mblocks);
+  const int width = min(p.group_n, ncb - grp * p.group_n);
+  const int in_grp = within - grp * p.group_n * mblocks;
+  const int cb = grp * p.group_n + in_grp % width;
+  const int nblk = cb * 8 + (blockIdx.x & 7), mrow0 = (in_grp / width) * ROWS;
   const int ks = blockIdx.y;
   if (nblk * 8 >= p.ntiles) return;                         // grid padded to a multiple of 8 column blocks
   const int chunks_total = p.K >> (F8 ? 7 : 6);             // chunk = 128 bytes of an x row
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     r2_wait_vm<0>();                                        // no DMA may land after the workgroup is gone
     if constexpr (DIAG) {
       if (lane == 0) {
-        long* d = reinterpret_cast<long*>(p.partial) + ((long)blockIdx.x * 12 + wave) * 4;
+        long* d = reinterpret_cast<long*>(p.partial) + ((long)blockIdx.x * 12 + wave) * 8;
         d[0] = d_vm; d[1] = d_bar; d[2] = d_issue; d[3] = n;
       }
     }
@@ -216,7 +225,8 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     int xs = 0, wsl = 0;
     const int xoff = (mh * (ROWS / 2) + l15) * 128;
     const int sw = (l15 >> 1) & 7;
-    long d_bar = 0, d_rd = 0, d_mfma = 0;
+    long d_bar = 0, d_rd = 0, d_mfma = 0, loop_c0 = 0, loop_r0 = 0;
+    if constexpr (DIAG) { loop_c0 = __builtin_amdgcn_s_memtime(); loop_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr bool HOLD = !F8 && !DIAG && G >= 2 && (G % 2) == 0;   // see the HOLD branch below
     u32x4 hwf[2][2], hxg[2][GS];                              // HOLD: fragments carried across chunks
     if constexpr (HOLD) {                                     // chunk 0 has nothing held: zero operands add zero
@@ -350,8 +360,9 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     }
     if constexpr (DIAG) {
       if (lane == 0) {
-        long* d = reinterpret_cast<long*>(p.partial) + ((long)blockIdx.x * 12 + wave) * 4;
+        long* d = reinterpret_cast<long*>(p.partial) + ((long)blockIdx.x * 12 + wave) * 8;
         d[0] = d_bar; d[1] = d_rd; d[2] = d_mfma; d[3] = n;
+        d[4] = __builtin_amdgcn_s_memtime() - loop_c0; d[5] = __builtin_amdgcn_s_memrealtime() - loop_r0;
       }
     }
   }
@@ -374,6 +385,12 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
   write_acc_tiles<MTW, 2>(p, acc, tile0, l15, quad, ks, mrow0 + mh * (ROWS / 2));
 }
 
+// column blocks per workgroup-order group (see the kernel); DLIA_GEMM_ROWS_GROUP overrides (A/B runs)
+static int order_group() {
+  static const int g = [] { const char* e = getenv("DLIA_GEMM_ROWS_GROUP"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 4; }();
+  return g;
+}
+
 template <int ROWS, bool F8>
 static void launch_rows(const GemmParams& p, hipStream_t stream) {
   static const bool once = [] {
@@ -383,8 +400,10 @@ static void launch_rows(const GemmParams& p, hipStream_t stream) {
   }();
   (void)once;
   const int nblocks8 = (p.ntiles / 8 + 7) / 8 * 8, mblocks = (p.M + ROWS - 1) / ROWS;
+  GemmParams q = p;
+  q.group_n = order_group();
   hipLaunchKernelGGL((gemm_rows_kernel<ROWS, F8>), dim3(nblocks8 * mblocks, p.splitk), dim3(kR2Threads), RowsCfg<ROWS>::Lds,
-                     stream, p);
+                     stream, q);
 }
 
 // Row-block size for more than 256 rows. 256-row blocks do the most work per DMA byte, but a shape
@@ -424,8 +443,10 @@ extern "C" void dlia_gemm_rows(const dlia::GemmParams* p, hipStream_t stream) {
     }();
     (void)once;
     const int nblocks8 = (p->ntiles / 8 + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
+    GemmParams q = *p;
+    q.group_n = order_group();
     hipLaunchKernelGGL((gemm_rows_kernel<256, false, true>), dim3(nblocks8 * mblocks, 1), dim3(kR2Threads),
-                       RowsCfg<256>::Lds, stream, *p);
+                       RowsCfg<256>::Lds, stream, q);
     return;
   }
   switch (row_block(*p)) {
