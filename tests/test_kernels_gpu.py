@@ -383,6 +383,15 @@ def test_gemm_large_m_row_block_tiers(K):
         K.large_gemm_kernel(prev)
 
 
+def test_gemm_large_m_grouped_workgroup_order(K):
+    """From 16 row blocks up the streaming kernel orders its workgroups in patches of 4 column blocks
+    per XCD. 4096 rows x 4224 columns = 33 column blocks, padded to 40: 5 per XCD, i.e. a full group
+    of 4 and a clamped group of 1; every output tile must still be computed exactly once."""
+    _gemm_case(K, 4096, 4224, 256, 0, 1)
+    _gemm_case(K, 4100, 1024, 256, 2, 1)         # 17 row blocks (the last one 4 rows), 1 column block per XCD
+    _gemm_a8w8_case(K, 4096, 4224, 256, 0, 1)
+
+
 def test_gemm_large_m_column_blocks_not_a_multiple_of_256(K, large_kernel):
     """N = 1152 packs to 72 n-tiles = 4.5 blocks of 256 columns: the last workgroup of the 256 x 256
     kernel has only half a block of real weight tiles."""
