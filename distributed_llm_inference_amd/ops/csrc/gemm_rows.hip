@@ -1,5 +1,5 @@
-// Weight-streaming bf16 GEMM with both operands moved by DMA: out[M,N] = epi(x[M,K] @ W[N,K]^T)
-// for M > 128 — decode batches of 129..256 rows (one row block, split-K partials available) and,
+// Weight-streaming GEMM (bf16, and e4m3 x e4m3: see F8 below) with both operands moved by DMA:
+// out[M,N] = epi(x[M,K] @ W[N,K]^T) for M > 128 — decode batches of 129..256 rows (one row block, split-K partials available) and,
 // above that, prefill chunks / large decode batches as a grid of 256-row blocks.
 //
 // A workgroup owns 256 x 128 outputs and walks K in 64-wide chunks. Every workgroup re-stages its
@@ -18,8 +18,9 @@
 //    instead of 59 (a wave blocked in a full memory queue issues no MFMAs).
 // The kernel is written for any ROWS in {32, 64, 128, 256} per workgroup (fewer rows shrink the x
 // stages and deepen the weight ring to 5-7 chunks), and those variants pass the numerics tests,
-// but up to 256 rows only ROWS = 256 is launched: measured at 1 / 64 / 128 rows a decode step takes 3.73 / 4.30 /
-// 5.41 ms with them against 3.58 / 4.31 / 5.41 ms with the register-ring kernels of
+// but up to 256 rows only ROWS = 256 is launched (the 128- and 64-row tiles serve the opt-in
+// "narrow" row-block policy above 256 rows, see row_block): measured at 1 / 64 / 128 rows a decode
+// step takes 3.73 / 4.30 / 5.41 ms with them against 3.58 / 4.31 / 5.41 ms with the register-ring kernels of
 // gemm_skinny.hip, which already stream the large shapes at the HBM ceiling there (gate/up
 // 5.3 TB/s at 64 rows) — a deeper ring has nothing left to hide.
 // Weights are the packed-B image (ops/packing.py): a (n-tile, k-step) block is 64 lanes x 16 B in
