@@ -27,6 +27,7 @@
 //
 // Replaces HF SDPA inside LlamaDecoderLayer, which the reference runs over the full S x S
 // problem on every step with no cache (Worker1.py:128-137, use_cache=False).
+#include <cstdlib>
 #include "common.h"
 #include "kv_layout.h"
 #include "launch.h"
@@ -217,8 +218,17 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
           pv[kt * 4 + r] = KV8 ? e * raw.sv[kt][r] : e;       // V's per-key scale rides in P^T
         }
       l[nt] = l[nt] * alpha + rs;
+      // The running maximum settles after the first blocks of a row; from then on alpha is exactly 1
+      // and rescaling the DT accumulator tiles (a third of this loop's VALU work) is a no-op. The
+      // prefill instantiations skip it unless some lane of the wave needs it (-4% on an 8192-token
+      // prompt). The decode instantiation must not: the branch stops the compiler from overlapping
+      // the prefetched K/V loads with the MFMAs and cost 13% of a whole Llama-3-8B decode step.
+      bool rescale = true;
+      if constexpr (NT > 1) rescale = __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0;
+      if (rescale) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt][nt] *= alpha;
+        for (int dt = 0; dt < DT; ++dt) o[dt][nt] *= alpha;
+      }
       pf[nt] = pack8(pv);     // element j: key 16*(j>>2) + 4*quad + (j&3) — the V slab's key order
     }
 #pragma unroll
@@ -344,6 +354,17 @@ template <int D, int NT>
 static void launch_attn(const AttnParams& p, hipStream_t stream) {
   const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
   constexpr size_t smem = 4 * NT * 64 * 2 * 4 + 4 * (D / 16) * NT * 64 * 16;
+  static_assert(smem <= 160 * 1024, "merge buffers must fit in LDS");
+  if constexpr (smem > 64 * 1024) {               // more than 64 KiB of dynamic LDS is opt-in, once per kernel
+    static const bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_attn_kernel<D, NT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_attn_kernel<D, NT, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      return true;
+    }();
+    (void)once;
+  }
   if (p.kv_scale) hipLaunchKernelGGL((paged_attn_kernel<D, NT, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   else            hipLaunchKernelGGL((paged_attn_kernel<D, NT, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   if (p.splits > 1)
@@ -355,8 +376,15 @@ static void launch_attn(const AttnParams& p, hipStream_t stream) {
 
 using namespace dlia;
 
-// Number of query columns per wave the launcher uses for a given chunk length.
-static inline int attn_nt(int max_q_len, int g) { return (max_q_len * g > 16) ? 2 : 1; }
+// Number of 16-column query tiles per workgroup for a given chunk length: 1 for decode, 2 for short
+// chunks, 4 for long prefill chunks — every workgroup streams the whole KV prefix of its query
+// positions from L2, so columns per workgroup is what the prefill kernel's arithmetic intensity is
+// (one 8192-token sequence: 17 GB of KV re-reads per layer at 32 columns).
+static inline int attn_nt(int max_q_len, int g) {
+  static const int cap = [] { const char* e = getenv("DLIA_ATTN_MAX_NT"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 ? v : 4; }();
+  const int nt = (max_q_len * g > 128) ? 4 : ((max_q_len * g > 16) ? 2 : 1);
+  return nt < cap ? nt : cap;
+}
 
 extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) {
   if (splits <= 1) return 0;
@@ -387,6 +415,9 @@ extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_
   const int nt = attn_nt(max_q_len, g);
   const int qt = (nt * 16) / g;
   p.qtiles = (max_q_len + qt - 1) / qt;
-  if (D == 128) { if (nt == 1) launch_attn<128, 1>(p, stream); else launch_attn<128, 2>(p, stream); }
-  else if (D == 64) { if (nt == 1) launch_attn<64, 1>(p, stream); else launch_attn<64, 2>(p, stream); }
+  if (D == 128) {
+    if (nt == 1) launch_attn<128, 1>(p, stream); else if (nt == 2) launch_attn<128, 2>(p, stream); else launch_attn<128, 4>(p, stream);
+  } else if (D == 64) {
+    if (nt == 1) launch_attn<64, 1>(p, stream); else if (nt == 2) launch_attn<64, 2>(p, stream); else launch_attn<64, 4>(p, stream);
+  }
 }
