@@ -1,6 +1,7 @@
 // Causal GQA attention over the paged, fragment-ordered KV cache (kv_layout.h).
 //
-// One kernel serves chunked prefill and single-token decode: a work item is
+// paged_attn_kernel serves single-token decode, short chunks and split-KV (prefill_attn_kernel
+// further down takes chunks of more than 128 query columns per sequence): a work item is
 // (sequence b, kv head, query tile, kv split) and is owned by one 4-wave workgroup whose waves
 // interleave the item's KV blocks and merge their (m, l, O) through LDS once at the end — the
 // main loop has no LDS traffic and no barriers.
@@ -28,6 +29,7 @@
 // Replaces HF SDPA inside LlamaDecoderLayer, which the reference runs over the full S x S
 // problem on every step with no cache (Worker1.py:128-137, use_cache=False).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "kv_layout.h"
 #include "launch.h"
@@ -350,21 +352,270 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prefill-shaped variant, used for chunks of more than 128 query columns per sequence.
+//
+// The kernel above gives every wave ALL query columns of the workgroup and a quarter of the KV
+// blocks, which is right for decode (few columns, the KV stream is the cost) and wrong for long
+// chunks: at 64 columns a wave holds 128 accumulator + 64 Q + 128 K/V registers, the compiler
+// parks the excess in AGPRs and a fifth of the kernel is v_accvgpr moves; the 131 KB merge buffer
+// leaves one wave per SIMD; counters on an 8192-token prompt show VALU active 59 % of resident
+// wave time, the matrix cores 17 %, memory waits 8 %.
+//
+// Here the 4 waves split the QUERY columns instead (32 each, 128 per workgroup) and share every
+// KV block through LDS. A (block, kv head) is K slab + V slab back to back in memory and already
+// in fragment order, so staging it is a linear copy (16 B per thread and piece) and a fragment
+// is one conflict-free ds_read_b128 at fragment*1 KiB + lane*16 (an e4m3 cache is widened to bf16
+// while it is staged, once per workgroup). Block k+1 is loaded global -> registers while block k
+// is computed, then written to the other buffer: one barrier per block.
+// No cross-wave merge, 33 KB of LDS, K/V are fetched once per 128 columns.
+// Softmax work per score is cut to what the hardware needs: raw v_exp_f32 (results below the
+// normal range flush to zero, which a probability may), one FMA instead of subtract + multiply,
+// the causal mask only in blocks that can reach the wave's diagonal, the accumulator rescale only
+// when some running maximum moved.
+// Exchange with lane^16 / lane^32 on the VALU (v_permlane16_swap: odd 16-lane rows of the first operand
+// <-> even rows of the second; v_permlane32_swap: upper half <-> lower half). With both operands = x
+// the two results hold, in every lane, its own value and its partner's, so a max or a sum over the
+// four lanes of a column is two swaps — no LDS round trip in the middle of the softmax chain, unlike
+// ds_bpermute.
+__device__ __forceinline__ float quad_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float quad_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <int D, bool KV8>
+__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
+  constexpr int KS = D / 32, DT = D / 16, NT = 2, NC = 128;
+  constexpr int BLOCK_BYTES = 2 * 2 * kBlockTokens * D;               // K slab + V slab of one head as bf16 (in LDS)
+  constexpr int MEM_BYTES = KV8 ? BLOCK_BYTES / 2 : BLOCK_BYTES;      // ... and as stored in the cache
+  constexpr int PIECES = MEM_BYTES / (256 * 16);
+  static_assert(PIECES >= 1 && PIECES * 256 * 16 == MEM_BYTES, "a block is whole 16-byte pieces per thread");
+  constexpr int BUF = BLOCK_BYTES + 256;                              // + the block's 64 fp32 scales (KV8)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, quad = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  long item = blockIdx.x;
+  const int qtile = p.qtiles - 1 - (int)(item % p.qtiles); item /= p.qtiles;   // longest KV prefix first
+  const int kvh = (int)(item % p.Hkv);
+  const int b = (int)(item / p.Hkv);
+
+  const int g = 1 << p.g_shift;
+  const int QT = NC >> p.g_shift;                 // query positions per workgroup
+  const int t0 = p.q_start[b];
+  const int q_len = p.q_start[b + 1] - t0;
+  const int ctx = p.ctx_lens[b];
+  int srow = p.slots ? p.slots[b] : b;
+  const bool srow_ok = srow >= 0 && srow < p.table_rows;
+  srow = srow_ok ? srow : 0;
+  const int qp0 = qtile * QT;
+  const bool tile_live = qp0 < q_len;             // workgroup-uniform
+
+  int col_qpos[NT]; long col_row[NT]; int col_head[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = wave * 32 + nt * 16 + l15;
+    const int qp = qp0 + (c >> p.g_shift);
+    col_qpos[nt] = (tile_live && qp < q_len) ? qp : -1;
+    col_row[nt] = (long)(t0 + (qp < q_len ? qp : 0));
+    col_head[nt] = kvh * g + (c & (g - 1));
+  }
+  // wave-uniform: first and last query position of this wave's columns
+  const int wq_first = qp0 + ((wave * 32) >> p.g_shift);
+  const int wq_last = min(q_len - 1, qp0 + ((wave * 32 + 31) >> p.g_shift));
+  const bool wave_live = tile_live && wq_first < q_len;
+  const int lim_first = ctx + wq_first;           // smallest "last visible key" among the wave's live columns
+  const int lim_last = ctx + wq_last;             // largest
+
+  const int tile_q_end = min(q_len, qp0 + QT);
+  const int kv_len = tile_live ? min(ctx + tile_q_end, p.max_blocks * kBlockTokens) : 0;
+  const int nb = (kv_len + kBlockTokens - 1) / kBlockTokens;      // workgroup-uniform
+
+  u32x4 qf[NT][KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (col_qpos[nt] >= 0)
+        qf[nt][s] = ld16(p.q + col_row[nt] * p.ldq + col_head[nt] * D + s * 32 + quad * 8);
+      else
+        qf[nt][s] = u32x4{0, 0, 0, 0};
+    }
+  f32x4 o[DT][NT];
+  float m[NT], l[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    m[nt] = kNegInf; l[nt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int* table = p.block_table + (long)srow * p.max_blocks;
+  u32x4 stage[PIECES];
+  f32x4 sstage = {0.f, 0.f, 0.f, 0.f};
+  auto gload = [&](int blk) {
+    blk = (srow_ok && blk >= 0 && blk < p.num_blocks) ? blk : 0;            // never a wild read
+    const char* src = reinterpret_cast<const char*>(p.kv) + kv_head_base(blk, kvh, p.Hkv, D, 0) * (KV8 ? 1 : 2);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) stage[i] = *reinterpret_cast<const u32x4*>(src + (i * 256 + tid) * 16);
+    if constexpr (KV8) {
+      if (tid < 16) sstage = *reinterpret_cast<const f32x4*>(p.kv_scale + kv_scale_base(blk, kvh, p.Hkv, 0) + tid * 4);
+    }
+  };
+  // KV8: a 16-byte piece of the cache is lane `lane`'s part of bf16 fragments 2R and 2R+1 (R = the
+  // piece's 1 KiB run, K runs first, then V). It is widened HERE, once per workgroup, so the four
+  // waves read plain bf16 fragments and the compute path is the bf16 one plus the two scale multiplies.
+  auto lstore = [&](int boff) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      if constexpr (KV8) {
+        const int run = i * 4 + (tid >> 6);
+        *reinterpret_cast<u32x4*>(smem + boff + (2 * run) * 1024 + lane * 16) = fp8x8_to_bf16x8(stage[i][0], stage[i][1]);
+        *reinterpret_cast<u32x4*>(smem + boff + (2 * run + 1) * 1024 + lane * 16) = fp8x8_to_bf16x8(stage[i][2], stage[i][3]);
+      } else {
+        *reinterpret_cast<u32x4*>(smem + boff + (i * 256 + tid) * 16) = stage[i];
+      }
+    }
+    if constexpr (KV8) {
+      if (tid < 16) *reinterpret_cast<f32x4*>(smem + boff + BLOCK_BYTES + tid * 16) = sstage;
+    }
+  };
+
+  auto process = [&](int kb, int boff, auto mask_c) {
+    constexpr bool MASK = decltype(mask_c)::value;
+    f32x4 sk[2], sv[2];
+    if constexpr (KV8) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        sk[kt] = *reinterpret_cast<const f32x4*>(smem + boff + BLOCK_BYTES + (kt * 16 + quad * 4) * 4);
+        sv[kt] = *reinterpret_cast<const f32x4*>(smem + boff + BLOCK_BYTES + (kBlockTokens + kt * 16 + quad * 4) * 4);
+      }
+    }
+    f32x4 st[2][NT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      u32x4 kf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const u32x4*>(smem + boff + (kt * KS + s) * 1024 + lane * 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a = mfma16(kf[s], qf[nt][s], a);
+        if constexpr (KV8) a *= sk[kt];
+        st[kt][nt] = a;
+      }
+    }
+    u32x4 pf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float mx = kNegInf;
+      if constexpr (MASK) {
+        const int limit = col_qpos[nt] >= 0 ? ctx + col_qpos[nt] : -1;   // last visible key position
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kpos = kb * kBlockTokens + kt * 16 + quad * 4 + r;
+            const float sc = kpos <= limit ? st[kt][nt][r] : kNegInf;
+            st[kt][nt][r] = sc;
+            mx = fmaxf(mx, sc);
+          }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][nt][r]);
+      }
+      mx = quad_max(mx);
+      const float m_new = fmaxf(m[nt], mx);
+      const float m_safe = m_new == kNegInf ? 0.f : m_new;
+      const float ms = m_safe * p.scale_log2;
+      const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m[nt], p.scale_log2, -ms));     // m = -inf -> 0
+      m[nt] = m_new;
+      float pv[8], rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][nt][r], p.scale_log2, -ms));   // masked: -inf -> 0
+          rs += e;
+          pv[kt * 4 + r] = KV8 ? e * sv[kt][r] : e;       // V's per-key scale rides in P^T
+        }
+      l[nt] = l[nt] * alpha + rs;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt][nt] *= alpha;
+      }
+      pf[nt] = pack8(pv);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const u32x4 vf = *reinterpret_cast<const u32x4*>(smem + boff + BLOCK_BYTES / 2 + dt * 1024 + lane * 16);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[dt][nt] = mfma16(vf, pf[nt], o[dt][nt]);
+    }
+  };
+
+  // The block table is read 64 entries at a time, one per lane; a block's entry is then a v_readlane:
+  // no memory access (and no wait on a memory counter) inside the loop except once per 64 blocks.
+  int tbl = 0;
+  auto tbl_fill = [&](int kb) { tbl = (kb + lane < p.max_blocks) ? table[kb + lane] : 0; };
+  auto tbl_at = [&](int kb) { return __builtin_amdgcn_readlane(tbl, kb & 63); };
+  tbl_fill(0);
+  if (nb > 0) { gload(tbl_at(0)); lstore(0); }
+  // Everything loaded so far (the Q fragments, block 0) has landed before the loop starts: vmcnt is
+  // one in-order counter, so a wait for a prologue load placed inside the loop would also wait for
+  // the prefetch of the next block that was issued just before it.
+  __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+  __syncthreads();
+  for (int kb = 0; kb < nb; ++kb) {
+    const int boff = (kb & 1) * BUF;
+    if (kb + 1 < nb) {
+      if (((kb + 1) & 63) == 0) tbl_fill(kb + 1);
+      gload(tbl_at(kb + 1));
+    }
+    if (wave_live && kb * kBlockTokens <= lim_last) {                 // else: every key of the block is masked for this wave
+      if (kb * kBlockTokens + kBlockTokens - 1 <= lim_first) process(kb, boff, std::false_type{});
+      else process(kb, boff, std::true_type{});
+    }
+    if (kb + 1 < nb) lstore(BUF - boff);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float lt = quad_sum(l[nt]);
+    if (col_qpos[nt] < 0) continue;
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x4 acc = o[dt][nt];
+      u32x2 v = {pack_bf16(acc[0] * inv, acc[1] * inv), pack_bf16(acc[2] * inv, acc[3] * inv)};
+      *reinterpret_cast<u32x2*>(p.out + col_row[nt] * p.ldo + col_head[nt] * D + dt * 16 + quad * 4) = v;
+    }
+  }
+}
+
+template <int D>
+static void launch_prefill_attn(const AttnParams& p, hipStream_t stream) {
+  const long nitems = (long)p.B * p.Hkv * p.qtiles;
+  constexpr size_t smem = 2 * (4 * kBlockTokens * D + 256);      // two bf16 blocks + their scales
+  if (p.kv_scale) hipLaunchKernelGGL((prefill_attn_kernel<D, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
+  else            hipLaunchKernelGGL((prefill_attn_kernel<D, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
+}
+
 template <int D, int NT>
 static void launch_attn(const AttnParams& p, hipStream_t stream) {
   const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
   constexpr size_t smem = 4 * NT * 64 * 2 * 4 + 4 * (D / 16) * NT * 64 * 16;
-  static_assert(smem <= 160 * 1024, "merge buffers must fit in LDS");
-  if constexpr (smem > 64 * 1024) {               // more than 64 KiB of dynamic LDS is opt-in, once per kernel
-    static const bool once = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_attn_kernel<D, NT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_attn_kernel<D, NT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      return true;
-    }();
-    (void)once;
-  }
   if (p.kv_scale) hipLaunchKernelGGL((paged_attn_kernel<D, NT, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   else            hipLaunchKernelGGL((paged_attn_kernel<D, NT, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   if (p.splits > 1)
@@ -376,14 +627,16 @@ static void launch_attn(const AttnParams& p, hipStream_t stream) {
 
 using namespace dlia;
 
-// Number of 16-column query tiles per workgroup for a given chunk length: 1 for decode, 2 for short
-// chunks, 4 for long prefill chunks — every workgroup streams the whole KV prefix of its query
-// positions from L2, so columns per workgroup is what the prefill kernel's arithmetic intensity is
-// (one 8192-token sequence: 17 GB of KV re-reads per layer at 32 columns).
-static inline int attn_nt(int max_q_len, int g) {
-  static const int cap = [] { const char* e = getenv("DLIA_ATTN_MAX_NT"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 ? v : 4; }();
-  const int nt = (max_q_len * g > 128) ? 4 : ((max_q_len * g > 16) ? 2 : 1);
-  return nt < cap ? nt : cap;
+// Number of 16-column query tiles per workgroup of paged_attn_kernel: 1 for decode, 2 for chunks.
+static inline int attn_nt(int max_q_len, int g) { return (max_q_len * g > 16) ? 2 : 1; }
+
+// Chunks of more than 128 query columns per sequence without split-KV go to the prefill-shaped
+// kernel (DLIA_ATTN_PREFILL=0 keeps them on paged_attn_kernel, for A/B runs). One 8192-token
+// Llama-3-8B prompt, whole model: 141.7 ms against 163.5 ms on paged_attn_kernel at 32 columns per
+// workgroup (158.4 ms at 64, a variant since removed); 16 x 512 tokens: 106.7 against 111.8 ms.
+static inline bool use_prefill_kernel(int max_q_len, int g, int splits) {
+  static const bool on = [] { const char* e = getenv("DLIA_ATTN_PREFILL"); return !(e && atoi(e) == 0); }();
+  return on && splits <= 1 && g <= 128 && max_q_len * g > 128;
 }
 
 extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) {
@@ -412,12 +665,14 @@ extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_
   p.max_blocks = max_blocks; p.num_blocks = num_blocks;
   p.splits = (splits > 1 && partial) ? splits : 1;
   p.scale_log2 = scale * 1.4426950408889634f;
+  if (use_prefill_kernel(max_q_len, g, p.splits) && (D == 128 || D == 64)) {
+    p.qtiles = (max_q_len + 128 / g - 1) / (128 / g);
+    if (D == 128) launch_prefill_attn<128>(p, stream); else launch_prefill_attn<64>(p, stream);
+    return;
+  }
   const int nt = attn_nt(max_q_len, g);
   const int qt = (nt * 16) / g;
   p.qtiles = (max_q_len + qt - 1) / qt;
-  if (D == 128) {
-    if (nt == 1) launch_attn<128, 1>(p, stream); else if (nt == 2) launch_attn<128, 2>(p, stream); else launch_attn<128, 4>(p, stream);
-  } else if (D == 64) {
-    if (nt == 1) launch_attn<64, 1>(p, stream); else if (nt == 2) launch_attn<64, 2>(p, stream); else launch_attn<64, 4>(p, stream);
-  }
+  if (D == 128) { if (nt == 1) launch_attn<128, 1>(p, stream); else launch_attn<128, 2>(p, stream); }
+  else if (D == 64) { if (nt == 1) launch_attn<64, 1>(p, stream); else launch_attn<64, 2>(p, stream); }
 }

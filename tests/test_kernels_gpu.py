@@ -544,6 +544,17 @@ def test_attention_prefill_ragged(K, geom):
     _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 0, 40, 96], q_lens=[77, 5, 33, 64], splits=1)
 
 
+@pytest.mark.parametrize("kv8", [False, True])
+@pytest.mark.parametrize("geom", [(32, 8, 128), (32, 4, 64), (12, 12, 64), (64, 8, 128), (8, 4, 64)])
+def test_attention_prefill_long_chunks(K, geom, kv8):
+    """Chunks of more than 128 query columns per sequence run on the prefill-shaped kernel (waves split the
+    query columns, KV blocks shared through LDS): several query tiles per sequence, a cached context of many
+    blocks (most of them on the unmasked path), a sequence shorter than one tile, MHA and GQA groups of 2-8."""
+    Hq, Hkv, D = geom
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 300, 37], q_lens=[300, 150, 3], splits=1, kv8=kv8)
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[1000], q_lens=[129], splits=1, seed=3, kv8=kv8)
+
+
 def test_attention_prefill_chunk_splitkv_norope(K):
     _attn_case(K, 12, 12, 64, ctx_lens=[130, 0], q_lens=[20, 50], splits=2, use_rope=False)
 
