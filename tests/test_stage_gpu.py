@@ -63,6 +63,45 @@ def test_prefill_and_eager_decode_match_reference(family):
         ctx = [c + 1 for c in ctx]
 
 
+@pytest.mark.parametrize("kv_dtype", ["bf16", "fp8"])
+@pytest.mark.parametrize("family", ["llama", "gpt2"])
+def test_long_prompt_in_chunks_matches_reference_in_one_piece(family, kv_dtype):
+    """A 300-token prompt prefilled as chunks of 160 + 140 tokens (each more than 128 query columns per
+    sequence, so both run on the prefill-shaped attention kernel, the second one over the cached context
+    the first one wrote) next to a short sequence, against the fp32 reference stage given the whole
+    prompt at once; then two decode steps over that cache."""
+    import dataclasses
+    from distributed_llm_inference_amd.models.stage_gpu import GpuStage
+    spec = dataclasses.replace(gpu_spec(family), max_position=512)
+    plan = make_plans(spec, 1)[0]
+    ref = RefStage(spec, plan, random_stage_weights(spec, plan, seed=4, dtype=torch.bfloat16).to(dtype=torch.float32))
+    gpu = GpuStage(spec, plan, random_stage_weights(spec, plan, seed=4, dtype=torch.bfloat16), max_slots=4, max_seq_len=512,
+                   num_blocks=40, max_tokens=320, max_batch=4, use_graphs=False, kv_dtype=kv_dtype)
+    torch.manual_seed(2)
+    long_p = torch.randint(3, spec.vocab_size, (300,), dtype=torch.int32)
+    short_p = torch.randint(3, spec.vocab_size, (9,), dtype=torch.int32)
+    tables = {1: list(range(20, 31)), 3: [2]}
+    lr = ref.forward(step([1, 3], [300, 9], [0, 0], tables=tables), torch.cat([long_p, short_p]))
+    gpu.forward(step([1, 3], [160, 9], [0, 0], tables=tables, sample=[0, 1]), torch.cat([long_p[:160], short_p]))
+    lg = gpu.forward(step([1], [140], [160]), long_p[160:])
+    tol = 1.0 if kv_dtype == "bf16" else 2.5         # the e4m3 cache adds quantisation noise to every key and value
+    a, b = lg.float().cpu()[0], lr.float().cpu()[0]
+    err, scale = (a - b).abs().max().item(), b.abs().max().item()
+    assert err <= tol * (0.05 * scale + 0.02), f"{family} {kv_dtype}: last-token logits of the chunked prompt: max err {err:.4f} vs scale {scale:.4f}"
+    if kv_dtype == "bf16":
+        assert int(a.argmax()) == int(b.argmax())
+    cur, ctx = lr.argmax(-1).to(torch.int32), [300, 9]
+    for i in range(2):
+        b_ = step([1, 3], [1, 1], ctx)
+        lr = ref.forward(b_, cur)
+        lg = gpu.forward(b_, cur)
+        a, b = lg.float().cpu(), lr.float().cpu()
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert err <= tol * (0.05 * scale + 0.02), f"{family} {kv_dtype}: decode step {i} after the chunked prefill: max err {err:.4f} vs scale {scale:.4f}"
+        cur = lr.argmax(-1).to(torch.int32)
+        ctx = [c + 1 for c in ctx]
+
+
 @pytest.mark.parametrize("family", ["llama", "gpt2"])
 def test_graph_decode_matches_reference_greedy(family):
     spec, ref, gpu = build(family, use_graphs=True)
