@@ -418,14 +418,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
   const int qp0 = qtile * QT;
   const bool tile_live = qp0 < q_len;             // workgroup-uniform
 
-  int col_qpos[NT]; long col_row[NT]; int col_head[NT];
+  // Column c = wave*32 + nt*16 + l15 is (query position qp0 + (c >> g_shift), head c & (g-1) of the group).
+  // Only the position stays in registers across the loop (the causal limit); token row and head are
+  // recomputed where they are needed, before and after it.
+  int col_qpos[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int c = wave * 32 + nt * 16 + l15;
-    const int qp = qp0 + (c >> p.g_shift);
+    const int qp = qp0 + ((wave * 32 + nt * 16 + l15) >> p.g_shift);
     col_qpos[nt] = (tile_live && qp < q_len) ? qp : -1;
-    col_row[nt] = (long)(t0 + (qp < q_len ? qp : 0));
-    col_head[nt] = kvh * g + (c & (g - 1));
   }
   // wave-uniform: first and last query position of this wave's columns
   const int wq_first = qp0 + ((wave * 32) >> p.g_shift);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (col_qpos[nt] >= 0)
-        qf[nt][s] = ld16(p.q + col_row[nt] * p.ldq + col_head[nt] * D + s * 32 + quad * 8);
+        qf[nt][s] = ld16(p.q + (long)(t0 + col_qpos[nt]) * p.ldq + (kvh * g + ((wave * 32 + nt * 16 + l15) & (g - 1))) * D + s * 32 + quad * 8);
       else
         qf[nt][s] = u32x4{0, 0, 0, 0};
     }
@@ -595,11 +595,15 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
     const float lt = quad_sum(l[nt]);
     if (col_qpos[nt] < 0) continue;
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    int le = lane;
+    asm volatile("" : "+v"(le));                   // recompute from the lane id instead of keeping the prologue's values live
+    const int ce = wave * 32 + nt * 16 + (le & 15);
+    bf16* orow = p.out + (long)(t0 + col_qpos[nt]) * p.ldo + (kvh * g + (ce & (g - 1))) * D + (le >> 4) * 4;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const f32x4 acc = o[dt][nt];
       u32x2 v = {pack_bf16(acc[0] * inv, acc[1] * inv), pack_bf16(acc[2] * inv, acc[3] * inv)};
-      *reinterpret_cast<u32x2*>(p.out + col_row[nt] * p.ldo + col_head[nt] * D + dt * 16 + quad * 4) = v;
+      *reinterpret_cast<u32x2*>(orow + dt * 16) = v;
     }
   }
 }
