@@ -93,6 +93,41 @@ def test_gpu_engine_tracks_torch_backend():
     assert sum(prefix) >= 0.5 * 12 * len(ps), prefix
 
 
+def test_long_prompts_chunked_by_the_scheduler_track_torch_backend():
+    """Prompts of up to 230 tokens with a 96-token prefill chunk: the scheduler splits them into 2-3 chunks, the
+    96-token ones (192 query columns at a GQA group of 2) run on the prefill-shaped attention kernel over the
+    context the earlier chunks cached, the remainders on the decode-shaped one. Same weights on the fp32 torch
+    pipeline with the same chunking: the first token and most of the greedy continuation agree."""
+    from distributed_llm_inference_amd.models.partition import make_plans
+    from distributed_llm_inference_amd.models.spec import ModelSpec
+    from distributed_llm_inference_amd.models.stage_gpu import GpuStage
+    from distributed_llm_inference_amd.models.stage_ref import RefStage
+    from distributed_llm_inference_amd.models.weights import random_stage_weights
+    g = torch.Generator().manual_seed(9)
+    ps = [torch.randint(3, 320, (n,), generator=g).tolist() for n in (230, 150, 97, 20, 192)]
+    spec = ModelSpec.from_pretrained(MODEL)
+    plan = make_plans(spec, 1)[0]
+    c = cfg(prefill_chunk=96)
+    gpu_ex = GpuStage(spec, plan, random_stage_weights(spec, plan, seed=3, dtype=torch.bfloat16),
+                      max_slots=c.num_micro_batches * c.max_batch, max_seq_len=c.max_seq_len, num_blocks=256,
+                      max_tokens=c.prefill_chunk, max_batch=c.max_batch)
+    ref_ex = RefStage(spec, plan, random_stage_weights(spec, plan, seed=3, dtype=torch.bfloat16).to(dtype=torch.float32),
+                      max_seq_len=c.max_seq_len)
+    gpu, snap = run(c, ps, greedy(10), executors=[gpu_ex])
+    assert snap["fatal"] is None
+    cpu, _ = run(cfg(prefill_chunk=96, backend="torch", device="cpu"), ps, greedy(10), executors=[ref_ex])
+    assert all(len(o) == 10 for o in gpu)
+    first_ok = sum(a[0] == b[0] for a, b in zip(gpu, cpu))
+    assert first_ok >= len(ps) - 1, (gpu, cpu)
+    prefix = []
+    for a, b in zip(gpu, cpu):
+        n = 0
+        while n < len(a) and a[n] == b[n]:
+            n += 1
+        prefix.append(n)
+    assert sum(prefix) >= 0.5 * 10 * len(ps), prefix
+
+
 def test_sampled_generation_is_reproducible_and_stops_at_cap():
     ps = prompts(9, seed=4)
     sp = SamplingParams(temperature=0.8, top_k=40, top_p=0.95, max_new_tokens=10, stop_on_eos=False, seed=11)
