@@ -50,6 +50,7 @@ struct AttnParams {
   int B, Hq, Hkv, g_shift;        // group size g = 1 << g_shift
   int max_blocks, num_blocks, qtiles, splits;
   float scale_log2;               // softmax scale * log2(e)
+  int xcd_map;                    // prefill kernel: (sequence, kv head) groups are dealt to XCDs (see there)
 };
 
 constexpr float kNegInf = -__builtin_inff();
@@ -402,10 +403,24 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, quad = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  long item = blockIdx.x;
-  const int qtile = p.qtiles - 1 - (int)(item % p.qtiles); item /= p.qtiles;   // longest KV prefix first
-  const int kvh = (int)(item % p.Hkv);
-  const int b = (int)(item / p.Hkv);
+  // Workgroup -> (sequence, kv head, query tile), longest KV prefix first. Workgroups go to the 8 XCDs
+  // round-robin by blockIdx and every XCD has its own L2. All query tiles of one (sequence, kv head)
+  // stream the same K/V, so with xcd_map (the number of such groups is a multiple of 8) group i runs
+  // entirely on XCD i % 8: an XCD's resident workgroups then walk ONE head's blocks at about the same
+  // time and hit in its L2, instead of every L2 seeing every head.
+  int qtile, kvh, b;
+  if (p.xcd_map) {
+    const int w = blockIdx.x >> 3;
+    const int grp = (blockIdx.x & 7) + 8 * (w / p.qtiles);
+    qtile = p.qtiles - 1 - (w % p.qtiles);
+    kvh = grp % p.Hkv;
+    b = grp / p.Hkv;
+  } else {
+    long item = blockIdx.x;
+    qtile = p.qtiles - 1 - (int)(item % p.qtiles); item /= p.qtiles;
+    kvh = (int)(item % p.Hkv);
+    b = (int)(item / p.Hkv);
+  }
 
   const int g = 1 << p.g_shift;
   const int QT = NC >> p.g_shift;                 // query positions per workgroup
@@ -635,9 +650,10 @@ using namespace dlia;
 static inline int attn_nt(int max_q_len, int g) { return (max_q_len * g > 16) ? 2 : 1; }
 
 // Chunks of more than 128 query columns per sequence without split-KV go to the prefill-shaped
-// kernel (DLIA_ATTN_PREFILL=0 keeps them on paged_attn_kernel, for A/B runs). One 8192-token
-// Llama-3-8B prompt, whole model: 141.7 ms against 163.5 ms on paged_attn_kernel at 32 columns per
-// workgroup (158.4 ms at 64, a variant since removed); 16 x 512 tokens: 106.7 against 111.8 ms.
+// kernel (DLIA_ATTN_PREFILL=0 keeps them on paged_attn_kernel, DLIA_ATTN_XCD_MAP=0 turns the XCD-aware
+// workgroup order off, both for A/B runs). One 8192-token Llama-3-8B prompt, whole model: 133.0 ms
+// (140.6 without the XCD order) against 163.5 ms on paged_attn_kernel at 32 columns per workgroup
+// (158.4 ms at 64, a variant since removed); 16 x 512 tokens: 106.5 against 111.8 ms.
 static inline bool use_prefill_kernel(int max_q_len, int g, int splits) {
   static const bool on = [] { const char* e = getenv("DLIA_ATTN_PREFILL"); return !(e && atoi(e) == 0); }();
   return on && splits <= 1 && g <= 128 && max_q_len * g > 128;
@@ -669,8 +685,11 @@ extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_
   p.max_blocks = max_blocks; p.num_blocks = num_blocks;
   p.splits = (splits > 1 && partial) ? splits : 1;
   p.scale_log2 = scale * 1.4426950408889634f;
+  p.xcd_map = 0;
   if (use_prefill_kernel(max_q_len, g, p.splits) && (D == 128 || D == 64)) {
     p.qtiles = (max_q_len + 128 / g - 1) / (128 / g);
+    static const bool xcd_on = [] { const char* e = getenv("DLIA_ATTN_XCD_MAP"); return !(e && atoi(e) == 0); }();
+    p.xcd_map = (xcd_on && ((long)B * Hkv) % 8 == 0) ? 1 : 0;
     if (D == 128) launch_prefill_attn<128>(p, stream); else launch_prefill_attn<64>(p, stream);
     return;
   }
