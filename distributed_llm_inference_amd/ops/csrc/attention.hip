@@ -446,7 +446,6 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
   const int wq_first = qp0 + ((wave * 32) >> p.g_shift);
   const int wq_last = min(q_len - 1, qp0 + ((wave * 32 + 31) >> p.g_shift));
   const bool wave_live = tile_live && wq_first < q_len;
-  const int lim_first = ctx + wq_first;           // smallest "last visible key" among the wave's live columns
   const int lim_last = ctx + wq_last;             // largest
 
   const int tile_q_end = min(q_len, qp0 + QT);
@@ -591,19 +590,29 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
   // the prefetch of the next block that was issued just before it.
   __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
   __syncthreads();
-  for (int kb = 0; kb < nb; ++kb) {
-    const int boff = (kb & 1) * BUF;
-    if (kb + 1 < nb) {
-      if (((kb + 1) & 63) == 0) tbl_fill(kb + 1);
-      gload(tbl_at(kb + 1));
+  // Two loops instead of one loop choosing between two inlined copies of process(): blocks that end at
+  // or below the smallest causal limit in the workgroup (wave 0's first column) need no mask in any
+  // wave; the last two or three blocks run the masked form, which is also right for a block that
+  // happens to need none. With both forms in one loop the accumulators lived in different registers
+  // in each and the compiler reconciled them with a dozen v_mov_b64 per block; VALU and MFMA time add
+  // up in this kernel (66 % + 32 % of SIMD time), so those copies were not free.
+  const int nb_full = tile_live ? min(nb, (ctx + qp0 + 1) / kBlockTokens) : 0;      // workgroup-uniform
+  auto run = [&](int kb_begin, int kb_end, auto mask_c) {
+    constexpr bool MASK = decltype(mask_c)::value;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      const int boff = (kb & 1) * BUF;
+      if (kb + 1 < nb) {
+        if (((kb + 1) & 63) == 0) tbl_fill(kb + 1);
+        gload(tbl_at(kb + 1));
+      }
+      // masked loop: a block whose first key is beyond the wave's last column is skipped altogether
+      if (wave_live && (!MASK || kb * kBlockTokens <= lim_last)) process(kb, boff, mask_c);
+      if (kb + 1 < nb) lstore(BUF - boff);
+      __syncthreads();
     }
-    if (wave_live && kb * kBlockTokens <= lim_last) {                 // else: every key of the block is masked for this wave
-      if (kb * kBlockTokens + kBlockTokens - 1 <= lim_first) process(kb, boff, std::false_type{});
-      else process(kb, boff, std::true_type{});
-    }
-    if (kb + 1 < nb) lstore(BUF - boff);
-    __syncthreads();
-  }
+  };
+  run(0, nb_full, std::false_type{});
+  run(nb_full, nb, std::true_type{});
 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -651,9 +660,9 @@ static inline int attn_nt(int max_q_len, int g) { return (max_q_len * g > 16) ? 
 
 // Chunks of more than 128 query columns per sequence without split-KV go to the prefill-shaped
 // kernel (DLIA_ATTN_PREFILL=0 keeps them on paged_attn_kernel, DLIA_ATTN_XCD_MAP=0 turns the XCD-aware
-// workgroup order off, both for A/B runs). One 8192-token Llama-3-8B prompt, whole model: 133.0 ms
-// (140.6 without the XCD order) against 163.5 ms on paged_attn_kernel at 32 columns per workgroup
-// (158.4 ms at 64, a variant since removed); 16 x 512 tokens: 106.5 against 111.8 ms.
+// workgroup order off, both for A/B runs). One 8192-token Llama-3-8B prompt, whole model: 126.0 ms
+// against 163.5 ms on paged_attn_kernel at 32 columns per workgroup (158.4 ms at 64, a variant since
+// removed); 16 x 512 tokens: 106.3 against 111.8 ms.
 static inline bool use_prefill_kernel(int max_q_len, int g, int splits) {
   static const bool on = [] { const char* e = getenv("DLIA_ATTN_PREFILL"); return !(e && atoi(e) == 0); }();
   return on && splits <= 1 && g <= 128 && max_q_len * g > 128;
