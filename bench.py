@@ -287,8 +287,8 @@ def main():
             "config": {"model": spec.name, "global_batch": global_batch, "seq_len": a.prompt_len,
                        "parallelism": f"pp{world}", "micro_batches": cfg.num_micro_batches,
                        "micro_batch_size": cfg.max_batch, "layer_ranges": plans,
-                       "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": cfg.use_graphs, "decode_streams": cfg.decode_streams,
-                       "backend": rt.ex.backend, "transport": cfg.resolved_transport(), "kv_cache": cfg.kv_dtype}}), flush=True)
+                       "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": bool(cfg.use_graphs and not a.cpu), "decode_streams": cfg.decode_streams,
+                       "backend": rt.ex.backend, "transport": cfg.resolved_transport(), "kv_cache": "fp32" if a.cpu else cfg.kv_dtype}}), flush=True)
     if world > 1:
         import torch.distributed as dist
         try:

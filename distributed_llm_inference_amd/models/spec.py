@@ -256,6 +256,7 @@ def _register_test_models():
     # resolvable by name in spawned stage processes too (tests of the multi-process pipeline)
     BUILTIN_SPECS["tiny-llama-test"] = tiny_spec("llama")
     BUILTIN_SPECS["tiny-gpt2-test"] = tiny_spec("gpt2")
+    BUILTIN_SPECS["tiny-llama-8l-test"] = tiny_spec("llama", name="tiny-llama-8l-test", num_layers=8)   # splits into 8 stages
     BUILTIN_SPECS["tiny-llama-gpu-test"] = tiny_spec(
         "llama", name="tiny-llama-gpu-test", hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
         intermediate_size=512, vocab_size=320, num_layers=4)

@@ -82,6 +82,33 @@ def test_pipeline_equals_single_stage(pp):
         many.close()
 
 
+def test_eight_stages_with_the_benchmark_partitioning_equal_one_stage():
+    """The shape bench.py runs on a full node: 8 stages from the balanced partitioner (embedding and lm_head
+    weighed in, so the first and last stage get fewer layers), twice as many micro-batches as stages, tokens
+    fed back from stage 7 to stage 0 — identical greedy tokens to the single-stage engine."""
+    from distributed_llm_inference_amd.models.spec import ModelSpec
+    from distributed_llm_inference_amd.parallel.launcher import plans_for
+    model = "tiny-llama-8l-test"
+    ps = prompts(21, seed=8)
+    one = LocalPipeline(cfg(model=model))
+    try:
+        want = run(one, ps, greedy(7))
+    finally:
+        one.close()
+    c = cfg(model=model, pp_size=8, num_micro_batches=16, max_batch=2, partition="balanced")
+    plans = plans_for(c, ModelSpec.from_pretrained(model))
+    assert len(plans) == 8 and plans[0].has_embed and plans[-1].has_head
+    assert sum(p.layer_end - p.layer_start for p in plans) == 8 and all(p.layer_end > p.layer_start for p in plans)
+    many = LocalPipeline(c)
+    try:
+        got = run(many, ps, greedy(7))
+        assert got == want
+        assert many.engine.snapshot()["completed"] == 21
+        assert all(many.board.read(s)["steps"] > 0 for s in range(8))
+    finally:
+        many.close()
+
+
 def test_uneven_and_explicit_partitions_agree():
     ps = prompts(3, seed=5)
     outs = []
