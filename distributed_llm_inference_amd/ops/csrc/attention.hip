@@ -50,7 +50,7 @@ struct AttnParams {
   int B, Hq, Hkv, g_shift;        // group size g = 1 << g_shift
   int max_blocks, num_blocks, qtiles, splits;
   float scale_log2;               // softmax scale * log2(e)
-  int xcd_map;                    // prefill kernel: (sequence, kv head) groups are dealt to XCDs (see there)
+  int xcd_map;                    // prefill kernel: 0 plain order, 1 group i on XCD i % 8, r > 1: r XCDs per group (see there)
 };
 
 constexpr float kNegInf = -__builtin_inff();
@@ -408,11 +408,20 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
   // stream the same K/V, so with xcd_map (the number of such groups is a multiple of 8) group i runs
   // entirely on XCD i % 8: an XCD's resident workgroups then walk ONE head's blocks at about the same
   // time and hit in its L2, instead of every L2 seeing every head.
+  // xcd_map > 1 (fewer than 8 groups, their number divides 8): every group owns xcd_map XCDs and its tiles
+  // are dealt over them, heaviest first; the grid is padded to whole rounds, surplus workgroups leave.
   int qtile, kvh, b;
-  if (p.xcd_map) {
+  if (p.xcd_map == 1) {
     const int w = blockIdx.x >> 3;
     const int grp = (blockIdx.x & 7) + 8 * (w / p.qtiles);
     qtile = p.qtiles - 1 - (w % p.qtiles);
+    kvh = grp % p.Hkv;
+    b = grp / p.Hkv;
+  } else if (p.xcd_map > 1) {
+    const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
+    const int grp = x / p.xcd_map;
+    qtile = p.qtiles - 1 - (w * p.xcd_map + x % p.xcd_map);
+    if (qtile < 0) return;                        // whole workgroup, before any barrier
     kvh = grp % p.Hkv;
     b = grp / p.Hkv;
   } else {
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
 
 template <int D>
 static void launch_prefill_attn(const AttnParams& p, hipStream_t stream) {
-  const long nitems = (long)p.B * p.Hkv * p.qtiles;
+  const long nitems = p.xcd_map > 1 ? 8L * ((p.qtiles + p.xcd_map - 1) / p.xcd_map) : (long)p.B * p.Hkv * p.qtiles;
   constexpr size_t smem = 2 * (4 * kBlockTokens * D + 256);      // two bf16 blocks + their scales
   if (p.kv_scale) hipLaunchKernelGGL((prefill_attn_kernel<D, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   else            hipLaunchKernelGGL((prefill_attn_kernel<D, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
@@ -698,7 +707,8 @@ extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_
   if (use_prefill_kernel(max_q_len, g, p.splits) && (D == 128 || D == 64)) {
     p.qtiles = (max_q_len + 128 / g - 1) / (128 / g);
     static const bool xcd_on = [] { const char* e = getenv("DLIA_ATTN_XCD_MAP"); return !(e && atoi(e) == 0); }();
-    p.xcd_map = (xcd_on && ((long)B * Hkv) % 8 == 0) ? 1 : 0;
+    const long groups = (long)B * Hkv;
+    p.xcd_map = !xcd_on ? 0 : (groups % 8 == 0 ? 1 : ((groups < 8 && 8 % groups == 0) ? (int)(8 / groups) : 0));
     if (D == 128) launch_prefill_attn<128>(p, stream); else launch_prefill_attn<64>(p, stream);
     return;
   }
