@@ -553,6 +553,10 @@ def test_attention_prefill_long_chunks(K, geom, kv8):
     Hq, Hkv, D = geom
     _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 300, 37], q_lens=[300, 150, 3], splits=1, kv8=kv8)
     _attn_case(K, Hq, Hkv, D, ctx_lens=[1000], q_lens=[129], splits=1, seed=3, kv8=kv8)
+    # two sequences: 8 / 16 / 24 (sequence, kv head) groups for every geometry, i.e. the workgroup order that puts
+    # group i on XCD i % 8 (the cases above have 12, 4 or 36 groups for the 64-wide heads: 8 / groups XCDs per
+    # group, or the plain order); `out` starts as NaN, so a tile the mapping missed would show
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[10, 200], q_lens=[140, 260], splits=1, seed=4, kv8=kv8)
 
 
 def test_attention_prefill_chunk_splitkv_norope(K):
