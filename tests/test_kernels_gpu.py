@@ -557,6 +557,9 @@ def test_attention_prefill_long_chunks(K, geom, kv8):
     # group i on XCD i % 8 (the cases above have 12, 4 or 36 groups for the 64-wide heads: 8 / groups XCDs per
     # group, or the plain order); `out` starts as NaN, so a tile the mapping missed would show
     _attn_case(K, Hq, Hkv, D, ctx_lens=[10, 200], q_lens=[140, 260], splits=1, seed=4, kv8=kv8)
+    # 600 tokens in one call: from 512 tokens up the KV write runs one workgroup per token for every geometry
+    # (below that a token's heads are spread over two); cache contents are compared exactly
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[0], q_lens=[600], splits=1, seed=6, kv8=kv8)
 
 
 def test_attention_prefill_chunk_splitkv_norope(K):
