@@ -27,6 +27,12 @@ import os
 import sys
 import time
 
+# A stage process drives up to six HIP streams (eager, two decode streams, token read-back, and one per
+# hop direction); with HIP's default of 4 hardware queues two of them would share a queue, and a
+# receive waiting for its peer at the head of a shared queue stalls the compute behind it — the
+# pipeline would run one micro-batch at a time. Read by the HIP runtime when it initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -59,9 +65,10 @@ def parse():
                          "fp8w: e4m3 weights only; KV cache and lm_head stay bf16 in both")
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: e4m3 KV cache with per-(token, head) scales (half the attention bytes; not the default)")
-    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "gloo"],
-                    help="activation transport between stages (auto: RCCL on GPUs; gloo = host-staged TCP, which "
-                         "also lets several stages share one GPU for a rehearsal)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "rccl-torch", "gloo"],
+                    help="activation transport between stages (auto / rccl: native ncclSend/ncclRecv hops, one "
+                         "communicator and stream per hop; rccl-torch: torch.distributed point-to-point; gloo = "
+                         "host-staged TCP, which also lets several stages share one GPU for a rehearsal)")
     ap.add_argument("--cpu", action="store_true", help="plumbing run on CPU (torch backend, gloo)")
     ap.add_argument("--max-seconds", type=float, default=1500.0,
                     help="abort the whole rank with an error instead of hanging if the run takes longer")
@@ -281,7 +288,10 @@ def main():
             "metric": "output tokens/sec (whole node), Llama-3-8B layer-split PP=N",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": (round(value / base, 1) if base else None), "dtype": "fp32" if a.cpu else {"bf16": "bf16", "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)", "fp8w": "fp8 weights, bf16 activations"}[a.dtype],
+            "vs_baseline": (round(value / base, 1) if base else None),
+            "vs_baseline_note": "baseline = the reference's own path re-enacted on the build host (CPU fp32, one request, "
+                                "full recompute per token, JSON over HTTP; bench/baseline_numbers.json) — not a like-for-like "
+                                "batch size", "dtype": "fp32" if a.cpu else {"bf16": "bf16", "fp8": "fp8 (e4m3 weights and activations, fp32 accumulate)", "fp8w": "fp8 weights, bf16 activations"}[a.dtype],
             "data": "synthetic prompts (random token ids), random-init weights",
             "p50_token_latency_ms": round(p50, 4),
             "config": {"model": spec.name, "global_batch": global_batch, "seq_len": a.prompt_len,

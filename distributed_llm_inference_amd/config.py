@@ -29,14 +29,15 @@ class EngineConfig:
     layer_ranges: Optional[List[Tuple[int, int]]] = None
     backend: str = "auto"                  # stage executor: "hip" | "torch" | "auto"
     device: str = "auto"                   # "cuda" | "cpu" | "auto"
-    transport: str = "auto"                # "rccl" | "gloo" | "loopback" | "http" | "auto"
+    transport: str = "auto"                # "rccl" (native hops) | "rccl-torch" | "gloo" | "loopback" | "http" | "auto"
+    isolate: bool = False                  # run even a single stage in its own process (the scheduler's process then holds no GPU context)
     # ---- batching / memory ------------------------------------------------------------
     max_batch: int = 64                    # sequences per micro-batch
     num_micro_batches: int = 0             # in-flight micro-batches (0 -> pp_size, >= 1)
     max_seq_len: int = 2048
     prefill_chunk: int = 2048              # max new tokens per prefill step
-    kv_blocks: int = 0                     # KV blocks per stage (0 -> from memory fraction / max_seq_len)
-    kv_mem_fraction: float = 0.85
+    kv_blocks: int = 0                     # KV blocks per stage (0 -> sized from free device memory, see kv_mem_fraction)
+    kv_mem_fraction: float = 0.85          # share of the memory left after weights and workspaces that the KV cache takes
     use_graphs: bool = True                # hipGraph-captured decode
     max_inflight_steps: int = 2            # steps of one micro-batch issued ahead of their results
     decode_streams: int = 3                # HIP streams the decode micro-batches of a stage alternate over
@@ -51,6 +52,7 @@ class EngineConfig:
     # ---- serving ------------------------------------------------------------------------
     host: str = "0.0.0.0"                  # orchestration.py:372
     port: int = 5000                       # orchestration.py:372; workers use 5001.. (Worker1.py:30)
+    server: str = "uvicorn"                # HTTP server of `serve`: "uvicorn" (ASGI) | "flask" (Werkzeug dev server, as the reference)
     worker_urls: List[str] = field(default_factory=list)   # http transport: one URL per worker
     request_timeout_s: float = 200.0       # Test.py:71
     hop_timeout_s: float = 30.0            # orchestration.py:118
@@ -111,7 +113,8 @@ class EngineConfig:
         if self.device != "auto":
             return self.device
         import torch
-        return "cuda" if torch.cuda.is_available() else "cpu"
+        # counting devices does not create a device context; the orchestrator process must not hold one
+        return "cuda" if torch.cuda.device_count() > 0 else "cpu"
 
     def resolved_backend(self) -> str:
         if self.backend != "auto":

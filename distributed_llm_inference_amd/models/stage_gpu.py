@@ -80,7 +80,13 @@ class GpuStage:
     def __init__(self, spec: ModelSpec, plan: StagePlan, weights: StageWeights, *, device="cuda",
                  max_slots: int = 256, max_seq_len: int = 2048, num_blocks: Optional[int] = None,
                  max_tokens: int = 2048, max_batch: int = 64, use_graphs: bool = True,
-                 kv_mem_fraction: float = 0.85, weight_dtype: str = "bf16", kv_dtype: str = "bf16"):
+                 kv_mem_fraction: float = 0.85, weight_dtype: str = "bf16", kv_dtype: str = "bf16",
+                 decode_states: int = 1, defer_kv: bool = False):
+        """`num_blocks`: KV blocks of this stage's cache; None sizes it from the device memory that is
+        free once weights and workspaces are resident (`kv_mem_fraction` of it, less what the
+        `decode_states` micro-batch workspaces will take). `defer_kv`: do not allocate the cache
+        yet — the caller reads `kv_budget_blocks()`, agrees on one count with the other stages and
+        calls `allocate_kv()`."""
         if not torch.cuda.is_available():
             raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
         if spec.head_dim not in (64, 128):
@@ -136,22 +142,6 @@ class GpuStage:
         else:
             self.cos = self.sin = torch.zeros(1, spec.head_dim // 2, device=dev)
 
-        # ---- paged KV cache for this stage's layers ---------------------------------------
-        L = plan.num_layers
-        # bytes of one block over this stage's layers (e4m3: 1 byte per element + a fp32 scale per token, head, K|V)
-        blk_bytes = L * spec.num_kv_heads * 2 * BLOCK * (spec.head_dim + 4 if self.kv8 else spec.head_dim * 2)
-        if num_blocks is None:
-            free, _ = torch.cuda.mem_get_info(dev)
-            budget = int(free * kv_mem_fraction) - self._workspace_bytes()
-            num_blocks = max(self.max_blocks, min(budget // max(blk_bytes, 1), max_slots * self.max_blocks))
-        self.num_blocks = int(num_blocks)
-        # zero-filled: masked-out (never written) slots must hold finite values, P=0 times NaN is NaN
-        self.kv = torch.zeros(max(L, 1), self.num_blocks, spec.num_kv_heads, 2, BLOCK * spec.head_dim,
-                              device=dev, dtype=torch.uint8 if self.kv8 else bf)
-        self.kv_scale = (torch.zeros(max(L, 1), self.num_blocks, spec.num_kv_heads, 2, BLOCK, device=dev)
-                         if self.kv8 else None)
-        self.block_table = torch.full((max_slots + 1, self.max_blocks), -1, device=dev, dtype=torch.int32)
-
         # ---- activation workspaces ----------------------------------------------------------
         self.max_splits = 16
         # split-K partial workspace [S, M, N]: one buffer per step in flight, reused by every GEMM
@@ -172,11 +162,20 @@ class GpuStage:
         self.md_tok_pos, self.md_tok_seq = i32(MT), i32(MT)
         self.md_q_start, self.md_ctx, self.md_slots = i32(max_batch + 1), i32(max_batch), i32(max_batch)
         self.md_rows, self.md_ids = i32(max_batch), i32(MT)
+        # ---- paged KV cache for this stage's layers ---------------------------------------
+        # (after the workspaces: the cache takes what is left of the device)
+        self.kv_mem_fraction, self.decode_states = kv_mem_fraction, max(1, decode_states)
+        self.kv = self.kv_scale = None
+        self.num_blocks = 0
+        self.block_table = torch.full((max_slots + 1, self.max_blocks), -1, device=dev, dtype=torch.int32)
+        if not defer_kv:
+            self.allocate_kv(num_blocks if num_blocks is not None else self.kv_budget_blocks())
         self._mbs: Dict[int, _MicroBatchState] = {}
         self._gemm_cfg: Dict[tuple, tuple] = {}
         self._ones = torch.ones(H, device=dev, dtype=bf)
         self.scale = 1.0 / math.sqrt(spec.head_dim)
         self.graph_replays = 0
+        self.graph_captures = 0
 
     def _new_work(self, rows: int) -> _Work:
         s, dev, bf = self.spec, self.device, torch.bfloat16
@@ -235,10 +234,45 @@ class GpuStage:
             self.K.paged_attention(attn, qkv, self.kv[li], q_start, ctx, self.block_table, slots, partial,
                                    max_q, s.num_heads, s.num_kv_heads, s.head_dim, self.scale, splits)
 
-    def _workspace_bytes(self) -> int:
+    # ---- KV cache sizing ------------------------------------------------------------------
+    def kv_block_bytes(self) -> int:
+        """Bytes of one 32-token block over this stage's layers (e4m3: one byte per element plus a
+        fp32 scale per token, kv head and K|V)."""
         s = self.spec
+        per_elem = (s.head_dim + 4) if self.kv8 else s.head_dim * 2
+        return max(1, self.plan.num_layers) * s.num_kv_heads * 2 * BLOCK * per_elem
+
+    def _decode_state_bytes(self) -> int:
+        """What one decode micro-batch will allocate on first use (activations, split-K partials,
+        logits), so the cache does not take memory the serving loop still needs."""
+        s, B = self.spec, self.max_batch
         per_tok = 2 * (2 * s.hidden_size + s.qkv_size + s.q_size + s.intermediate_size)
-        return self.max_tokens * per_tok + (1 << 30)
+        n = B * per_tok + 4 * self._ws_floats + 4 * self.wk0.attn_ws.numel()
+        if self.plan.has_head:
+            n += B * (4 * self.vocab_pad + 2 * s.hidden_size)
+        if self.wmode == "fp8":
+            n += B * max(s.hidden_size, s.q_size, s.intermediate_size)
+        return n
+
+    def kv_budget_blocks(self, share: float = 1.0) -> int:
+        """Blocks the cache may hold: `kv_mem_fraction` of the memory free right now (weights and
+        the eager workspace are resident), times `share` when several stages split one device, less
+        the decode micro-batch workspaces and 2 GiB for communicators, graphs and fragmentation;
+        never more than every slot at full length could use."""
+        torch.cuda.empty_cache()               # blocks cached by the weight packing count as free
+        free, _ = torch.cuda.mem_get_info(self.device)
+        budget = int(free * self.kv_mem_fraction * share) - self.decode_states * self._decode_state_bytes() - (2 << 30)
+        blocks = budget // self.kv_block_bytes()
+        return int(max(16, min(blocks, self.max_slots * self.max_blocks)))
+
+    def allocate_kv(self, num_blocks: int):
+        s, L, dev = self.spec, self.plan.num_layers, self.device
+        self.num_blocks = int(num_blocks)
+        # zero-filled: masked-out (never written) slots must hold finite values, P=0 times NaN is NaN
+        self.kv = torch.zeros(max(L, 1), self.num_blocks, s.num_kv_heads, 2, BLOCK * s.head_dim,
+                              device=dev, dtype=torch.uint8 if self.kv8 else torch.bfloat16)
+        self.kv_scale = (torch.zeros(max(L, 1), self.num_blocks, s.num_kv_heads, 2, BLOCK, device=dev)
+                         if self.kv8 else None)
 
     # ---- block tables ---------------------------------------------------------------------
     def set_tables(self, batch: StepBatch):
@@ -250,6 +284,19 @@ class GpuStage:
             row = torch.full((self.max_blocks,), -1, dtype=torch.int32)
             row[:len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
             self.block_table[slot].copy_(row.to(self.device, non_blocking=False))
+
+    def apply_growth(self, batch: StepBatch):
+        """block_table[slot][pos] = block for the sequences that got one more block this step.
+        Enqueued on the current stream, i.e. ahead of the step (graph replay included)."""
+        n = len(batch.grow_slots)
+        if n == 0:
+            return
+        for slot, pos, blk in zip(batch.grow_slots, batch.grow_pos, batch.grow_blocks):
+            if not (0 <= slot < self.max_slots and 0 <= pos < self.max_blocks and 0 <= blk < self.num_blocks):
+                raise ValueError(f"bad block-table growth: slot {slot} pos {pos} block {blk}")
+        idx = torch.tensor([s_ * self.max_blocks + p_ for s_, p_ in zip(batch.grow_slots, batch.grow_pos)], dtype=torch.int64)
+        val = torch.tensor(batch.grow_blocks, dtype=torch.int32)
+        self.block_table.view(-1).index_copy_(0, idx.to(self.device), val.to(self.device))
 
     def release(self, slots: List[int]):
         for s in slots:
@@ -356,6 +403,7 @@ class GpuStage:
             raise ValueError(f"step with {B} sequences / {T} tokens exceeds the stage limits "
                              f"({self.max_batch} / {self.max_tokens})")
         self.set_tables(batch)
+        self.apply_growth(batch)
         wk = self.wk0
         tok_pos, tok_seq, q_start, rows = [], [], [0], []
         for slot, q, c, smp in zip(batch.slots, batch.q_lens, batch.ctx_lens, batch.sample):
@@ -463,6 +511,7 @@ class GpuStage:
         if not hasattr(self, "_arange"):
             self._arange = torch.arange(self.max_batch + 1, device=self.device, dtype=torch.int32)
         st = self._mb_state(batch.micro_batch, B)
+        self.apply_growth(batch)
         if not batch.replay:
             self.set_tables(batch)
             dev = self.device
@@ -529,6 +578,7 @@ class GpuStage:
             self._decode_body(st)
         st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
         st.graph = g
+        self.graph_captures += 1
 
     # ---- introspection ----------------------------------------------------------------------
     def memory_report(self) -> Dict[str, float]:

@@ -92,6 +92,29 @@ def build(verbose: bool = True, force: bool = False) -> str:
         if verbose:
             print(f"[dlia.build] linked {out}", flush=True)
     build_runtime(verbose=verbose, force=force)
+    build_comm(verbose=verbose, force=force)
+    return out
+
+
+def build_comm(verbose: bool = True, force: bool = False) -> str:
+    """Native communication + stage-loop library (`csrc/comm/*.cpp` -> `ops/_comm.so`): host C++ on
+    the HIP runtime API; RCCL itself is resolved at run time from the library PyTorch loads. Linked
+    against the HIP runtime PyTorch ships so that a process never holds two of them."""
+    import torch
+    cdir = os.path.join(CSRC, "comm")
+    out = os.path.join(HERE, "_comm.so")
+    if not os.path.isdir(cdir):
+        return out
+    srcs = sorted(os.path.join(cdir, f) for f in os.listdir(cdir) if f.endswith(".cpp"))
+    deps = srcs + [os.path.join(cdir, f) for f in os.listdir(cdir) if f.endswith(".h")]
+    if srcs and (force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)):
+        rocm = os.environ.get("ROCM_HOME", "/opt/rocm")
+        tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-D__HIP_PLATFORM_AMD__=1",
+              f"-I{rocm}/include", *srcs, "-o", out, f"-L{tlib}", "-lamdhip64", "-ldl", "-lrt",
+              f"-Wl,-rpath,{tlib}"])
+        if verbose:
+            print(f"[dlia.build] linked {out}", flush=True)
     return out
 
 

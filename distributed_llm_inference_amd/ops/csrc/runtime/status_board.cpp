@@ -25,7 +25,9 @@ struct alignas(128) StageRecord {
   std::atomic<int32_t> state;          // 0 unregistered, 1 starting, 2 ready, 3 error, 4 stopped
   int32_t layer_start, layer_end;
   char error[64];
+  std::atomic<int64_t> kv_blocks;      // KV blocks this stage's HBM budget allows (0 = not known yet)
 };
+static_assert(sizeof(StageRecord) == 128, "one record per 128-byte line");
 
 struct Board {
   uint32_t magic;
@@ -102,14 +104,18 @@ void dlia_board_beat(void* hd, int stage, int64_t steps, int64_t tokens, int64_t
   r.heartbeat_ns.store(now_ns());
 }
 
+void dlia_board_set_kv(void* hd, int stage, int64_t blocks) {
+  static_cast<Handle*>(hd)->b->rec[stage].kv_blocks.store(blocks);
+}
+
 // out[0]=state out[1]=pid out[2]=age_ms of the heartbeat out[3]=steps out[4]=tokens out[5]=busy_ns
-// out[6]=layer_start out[7]=layer_end
+// out[6]=layer_start out[7]=layer_end out[8]=kv_blocks
 void dlia_board_read(void* hd, int stage, int64_t* out, char* err_out, int err_cap) {
   StageRecord& r = static_cast<Handle*>(hd)->b->rec[stage];
   out[0] = r.state.load(); out[1] = r.pid.load();
   out[2] = (now_ns() - r.heartbeat_ns.load()) / 1000000;
   out[3] = r.steps_done.load(); out[4] = r.tokens_done.load(); out[5] = r.busy_ns.load();
-  out[6] = r.layer_start; out[7] = r.layer_end;
+  out[6] = r.layer_start; out[7] = r.layer_end; out[8] = r.kv_blocks.load();
   if (err_out && err_cap > 0) { strncpy(err_out, r.error, err_cap - 1); err_out[err_cap - 1] = 0; }
 }
 

@@ -52,12 +52,27 @@ def plans_for(cfg: EngineConfig, spec: ModelSpec) -> List[StagePlan]:
 
 
 def kv_blocks_for(cfg: EngineConfig) -> int:
-    """Blocks every stage's cache is built with. The scheduler's allocator uses the same number,
-    so a block id valid on one stage is valid on all."""
+    """KV blocks when the count does not come from device memory: the configured number, or (torch
+    executor, whose cache is not paged) enough for every slot at full length."""
     if cfg.kv_blocks > 0:
         return cfg.kv_blocks
     per_seq = (cfg.max_seq_len + 31) // 32
     return cfg.num_micro_batches * cfg.max_batch * per_seq
+
+
+def ctrl_slot_bytes(cfg: EngineConfig) -> int:
+    """Slot size of the descriptor rings: the largest step descriptor this configuration can emit
+    (per-row fields of a full micro-batch, a prefill chunk's token ids, the block table of the
+    longest admissible prompt for every sequence of a chunk, growth entries), rounded up to a
+    power of two. Checked here, at configuration time, not when a descriptor first overflows."""
+    per_seq_blocks = (cfg.max_seq_len + 31) // 32
+    chunk = max(cfg.prefill_chunk, cfg.max_batch)
+    n = 64 + 40 * cfg.max_batch + 4 * chunk + 4 * (2 * cfg.max_batch + chunk // 32 + per_seq_blocks + cfg.max_batch) \
+        + 12 * cfg.max_batch + 4096
+    size = 1 << 16
+    while size < n:
+        size <<= 1
+    return size
 
 
 def load_weights(cfg: EngineConfig, spec: ModelSpec, plan: StagePlan, device: str, dtype) -> StageWeights:
@@ -67,23 +82,39 @@ def load_weights(cfg: EngineConfig, spec: ModelSpec, plan: StagePlan, device: st
     return random_stage_weights(spec, plan, seed=cfg.seed, device=device, dtype=dtype)
 
 
-def build_executor(cfg: EngineConfig, spec: ModelSpec, plan: StagePlan, device: Optional[str] = None):
+def build_executor(cfg: EngineConfig, spec: ModelSpec, plan: StagePlan, device: Optional[str] = None,
+                   defer_kv: bool = False):
+    """The stage executor for `plan`. HIP backend: `cfg.kv_blocks` > 0 fixes the cache size, else it
+    is sized from the device memory left after weights and workspaces (`kv_mem_fraction`); with
+    `defer_kv` the cache is allocated later by `settle_kv` (the stages first agree on one count)."""
     backend = cfg.resolved_backend()
     dev = device or cfg.resolved_device()
     if backend == "hip":
         from ..models.stage_gpu import GpuStage
         w = load_weights(cfg, spec, plan, dev, torch.bfloat16)
         return GpuStage(spec, plan, w, device=dev, max_slots=cfg.num_micro_batches * cfg.max_batch,
-                        max_seq_len=cfg.max_seq_len, num_blocks=kv_blocks_for(cfg),
+                        max_seq_len=cfg.max_seq_len, num_blocks=cfg.kv_blocks if cfg.kv_blocks > 0 else None,
                         max_tokens=cfg.prefill_chunk, max_batch=cfg.max_batch, use_graphs=cfg.use_graphs,
                         kv_mem_fraction=cfg.kv_mem_fraction, weight_dtype=cfg.dtype if cfg.dtype in ("fp8", "fp8w") else "bf16",
-                        kv_dtype=cfg.kv_dtype)
+                        kv_dtype=cfg.kv_dtype, decode_states=cfg.num_micro_batches, defer_kv=defer_kv)
     if cfg.kv_dtype != "bf16":
         raise ValueError(f"kv_dtype {cfg.kv_dtype!r} needs the hip backend (the torch executor keeps its cache in the compute dtype)")
     from ..models.stage_ref import RefStage
     dt = torch.float32 if cfg.dtype in ("fp32", "bf16") and dev == "cpu" else torch.bfloat16
     w = load_weights(cfg, spec, plan, "cpu", torch.float32)
     return RefStage(spec, plan, w, dtype=dt, device=dev, max_seq_len=cfg.max_seq_len)
+
+
+def kv_budget(cfg: EngineConfig, ex, share: float = 1.0) -> int:
+    """Blocks this stage could hold: from its device memory (HIP) or the configured / full-length count."""
+    if cfg.kv_blocks > 0 or not hasattr(ex, "kv_budget_blocks"):
+        return kv_blocks_for(cfg)
+    return ex.kv_budget_blocks(share)
+
+
+def settle_kv(ex, blocks: int):
+    if hasattr(ex, "allocate_kv") and ex.kv is None:
+        ex.allocate_kv(blocks)
 
 
 def make_tokenizer(cfg: EngineConfig, spec: ModelSpec):
@@ -103,7 +134,12 @@ class LocalPipeline:
         self.job = f"dlia_{os.getpid()}_{uuid.uuid4().hex[:8]}"
         self.board = StatusBoard(self.job + "_b", create=True, num_stages=cfg.pp_size)
         links = make_loopback_links(cfg.pp_size)
-        exs = executors or [build_executor(cfg, self.spec, p) for p in self.plans]
+        exs = executors or [build_executor(cfg, self.spec, p, defer_kv=True) for p in self.plans]
+        # every stage's cache holds the same number of blocks: the smallest budget (the stages of an
+        # in-process pipeline split one device between them)
+        self.kv_blocks = min(kv_budget(cfg, ex, 1.0 / len(exs)) for ex in exs)
+        for ex in exs:
+            settle_kv(ex, self.kv_blocks)
         self.executors = exs
         self.tracer = make_tracer(cfg.trace_path)      # one process: all stages share the tracer
         self.runtimes = [StageRuntime(ex, l, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
@@ -111,6 +147,7 @@ class LocalPipeline:
                          for ex, l in zip(exs, links)]
         for p in self.plans:
             self.board.register(p.stage, p.layer_start, p.layer_end)
+            self.board.set_kv_blocks(p.stage, self.kv_blocks)
         self.board.set_state(0, ST_READY)
         self.threads = []
         for rt in self.runtimes[1:]:
@@ -118,7 +155,7 @@ class LocalPipeline:
             t.start()
             self.threads.append(t)
         self.tokenizer = make_tokenizer(cfg, self.spec)
-        self.engine = Engine(cfg, self.runtimes[0], self.tokenizer, kv_blocks_for(cfg), board=self.board,
+        self.engine = Engine(cfg, self.runtimes[0], self.tokenizer, self.kv_blocks, board=self.board,
                              tracer=self.tracer).start()
 
     @staticmethod
@@ -144,128 +181,178 @@ def _free_port() -> int:
 
 
 def init_distributed(rank: int, world: int, backend: str, master_port: int, device: Optional[str]):
+    """Default process group of a multi-process pipeline. With the native RCCL transport it is gloo:
+    it carries communicator ids, barriers and the benchmark's max-over-ranks, never activations."""
     import datetime
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ["MASTER_PORT"] = str(master_port)       # not setdefault: a rebuilt pipeline gets a new port
-    kw = {}
-    if backend == "nccl" and device is not None:
+    if device is not None and device.startswith("cuda"):
         torch.cuda.set_device(torch.device(device))
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=600), **kw)
+                                timeout=datetime.timedelta(seconds=600))
     return dist
 
 
+def _group_backend(transport: str) -> str:
+    """torch.distributed backend of the default group for a transport: the native RCCL hops and
+    gloo both use a gloo group; "rccl-torch" moves activations through ProcessGroupNCCL itself."""
+    return {"rccl": "gloo", "gloo": "gloo", "rccl-torch": "nccl", "nccl": "nccl"}.get(transport, "gloo")
+
+
 def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, master_port: int,
-                        local_rank: Optional[int] = None):
-    """Common bring-up of one stage process. Returns (spec, plan, executor, links, board)."""
+                        local_rank: Optional[int] = None, create_board: Optional[bool] = None):
+    """Common bring-up of one stage process. Returns (spec, plan, executor, links, board).
+    `create_board`: whether this process creates the status board (default: rank 0 does; the
+    stages of a `SpawnedPipeline` all attach to the one their parent created)."""
     dev_kind = cfg.resolved_device()
     transport = cfg.resolved_transport()
-    backend = {"rccl": "nccl", "nccl": "nccl", "gloo": "gloo"}.get(transport, "gloo")
-    device = "cpu"
+    backend = _group_backend(transport)
+    device, share = "cpu", 1.0
     if dev_kind == "cuda":
         idx = rank if local_rank is None else local_rank
         ndev = torch.cuda.device_count()
-        if idx >= ndev > 0 and (backend == "gloo" or os.environ.get("DLIA_SHARE_GPU") == "1"):
+        if idx >= ndev > 0 and (transport == "gloo" or os.environ.get("DLIA_SHARE_GPU") == "1"):
             # more stages than GPUs: only the host-staged transport can share a device between ranks
             # (RCCL refuses two ranks on one GPU); used to rehearse a multi-stage job on a small box
+            share = 1.0 / ((world + ndev - 1) // ndev)
             idx %= ndev
+        elif ndev > 0 and world > ndev and transport == "gloo":
+            share = 1.0 / ((world + ndev - 1) // ndev)
         device = f"cuda:{idx}"
-    if dev_kind == "cuda":
         torch.cuda.set_device(torch.device(device))
     spec = resolve_spec(cfg)
     plan = plans_for(cfg, spec)[rank]
-    board = StatusBoard(job + "_b", create=(rank == 0), num_stages=world)
+    board = StatusBoard(job + "_b", create=(rank == 0) if create_board is None else create_board, num_stages=world)
     board.register(rank, plan.layer_start, plan.layer_end)
     try:
         if world > 1:
             init_distributed(rank, world, backend, master_port, device if dev_kind == "cuda" else None)
-        ex = build_executor(cfg, spec, plan, device=device)
-        links = (make_dist_links(rank, world, backend, job, host_staged=(dev_kind == "cuda" and backend == "gloo"))
-                 if world > 1 else make_loopback_links(1)[0])
+        ex = build_executor(cfg, spec, plan, device=device, defer_kv=True)
+        settle_kv(ex, board.agree_kv_blocks(rank, kv_budget(cfg, ex, share)))
+        slot = ctrl_slot_bytes(cfg)
+        if world == 1:
+            links = make_loopback_links(1)[0]
+        elif transport == "rccl" and dev_kind == "cuda":
+            from .transport import make_rccl_links
+            links = make_rccl_links(rank, world, job, device, ctrl_slot_bytes=slot)
+        else:
+            links = make_dist_links(rank, world, backend, job, host_staged=(dev_kind == "cuda" and backend == "gloo"),
+                                    ctrl_slot_bytes=slot)
     except BaseException as e:
         board.set_state(rank, ST_ERROR, f"{type(e).__name__}: {e}")
         raise
     return spec, plan, ex, links, board
 
 
-def _worker_entry(cfg_dict: dict, rank: int, world: int, job: str, master_port: int):
+def _stage_entry(cfg_dict: dict, rank: int, world: int, job: str, master_port: int):
+    """Body of one spawned stage process: stage 0 serves the scheduler's descriptor ring
+    (`head_main`), every other stage the ring of its predecessor (`stage_main`)."""
+    from ..runtime.head import head_main
+    from .transport import ShmControl
     cfg = EngineConfig.from_dict(cfg_dict)
-    spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, master_port)
-    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path), decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
-                      trace_path=cfg.trace_path)
+    spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, master_port, create_board=False)
+    rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path),
+                      decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5, trace_path=cfg.trace_path)
     try:
-        stage_main(rt)
+        if rank == 0:
+            cin = ShmControl(f"{job}_cin", create=False)
+            res = ShmControl(f"{job}_res", create=False)
+            head_main(rt, cin, res)
+        else:
+            stage_main(rt)
     finally:
         links.close()
 
 
 class SpawnedPipeline:
-    """Rank 0 (this process: scheduler + stage 0) plus P-1 spawned stage processes."""
+    """One OS process per stage (rank = stage = GPU), all of them children of this process, which
+    keeps only the scheduler: it holds no device context and no communicator, reaches stage 0
+    through two shared-memory rings, and can therefore always kill and replace the stages — also
+    when one of them sits in a device call that will never return."""
 
-    def __init__(self, cfg: EngineConfig):
+    def __init__(self, cfg: EngineConfig, ready_timeout: float = 600.0):
         import multiprocessing as mp
         from ..runtime.engine import Engine
+        from ..runtime.head import RemoteHead
+        from .transport import ShmControl
         self.cfg = cfg
         world = cfg.pp_size
         self.job = f"dlia_{os.getpid()}_{uuid.uuid4().hex[:8]}"
         port = _free_port()
         ctx = mp.get_context("spawn")
-        self.procs = []
-        # the status board must exist before the children attach
+        self.spec = resolve_spec(cfg)
+        self.plans = plans_for(cfg, self.spec)
+        # board and scheduler rings exist before the children attach
         self.board = StatusBoard(self.job + "_b", create=True, num_stages=world)
-        for r in range(1, world):
-            p = ctx.Process(target=_worker_entry, args=(cfg.to_dict(), r, world, self.job, port), daemon=True)
+        slot = ctrl_slot_bytes(cfg)
+        self.cin = ShmControl(f"{self.job}_cin", create=True, slot_bytes=slot)
+        self.res = ShmControl(f"{self.job}_res", create=True, slot_bytes=max(1 << 14, 64 + 4 * cfg.max_batch + 2048))
+        self.procs = []
+        self.engine = None
+        for r in range(world):
+            p = ctx.Process(target=_stage_entry, args=(cfg.to_dict(), r, world, self.job, port), daemon=True)
             p.start()
             self.procs.append(p)
-        dev_kind = cfg.resolved_device()
-        device = "cuda:0" if dev_kind == "cuda" else "cpu"
-        backend = {"rccl": "nccl", "nccl": "nccl", "gloo": "gloo"}.get(cfg.resolved_transport(), "gloo")
-        self.spec = resolve_spec(cfg)
-        self.plan = plans_for(cfg, self.spec)[0]
-        self.board.register(0, self.plan.layer_start, self.plan.layer_end)
         try:
-            init_distributed(0, world, backend, port, device if dev_kind == "cuda" else None)
-            ex = build_executor(cfg, self.spec, self.plan, device=device)
-            self.links = make_dist_links(0, world, backend, self.job,
-                                         host_staged=(dev_kind == "cuda" and backend == "gloo"))
-        except BaseException as e:
-            self.board.set_state(0, ST_ERROR, f"{type(e).__name__}: {e}")
+            self.wait_ready(ready_timeout)
+        except BaseException:
+            self.kill()
             raise
+        self.kv_blocks = min(self.board.read(s)["kv_blocks"] for s in range(world))
+        hip = cfg.resolved_backend() == "hip"
+        head = RemoteHead(self.spec, world, self.cin, self.res, graph_capable=hip, graph_rows=cfg.max_batch,
+                          debug_top5=cfg.debug_top5, timeout_s=cfg.hop_timeout_s * world)
         self.tracer = make_tracer(cfg.trace_path)
-        self.runtime = StageRuntime(ex, self.links, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
-                                    trace_path=cfg.trace_path)
-        self.board.set_state(0, ST_READY)
         self.tokenizer = make_tokenizer(cfg, self.spec)
-        self.engine = Engine(cfg, self.runtime, self.tokenizer, kv_blocks_for(cfg), board=self.board,
-                             tracer=self.tracer).start()
+        self.engine = Engine(cfg, head, self.tokenizer, self.kv_blocks, board=self.board, tracer=self.tracer).start()
 
     def wait_ready(self, timeout: float = 300.0):
         t0 = time.time()
         while time.time() - t0 < timeout:
-            states = [self.board.read(s)["state"] for s in range(self.cfg.pp_size)]
-            if all(s == "ready" for s in states):
+            recs = [self.board.read(s) for s in range(self.cfg.pp_size)]
+            if all(r["state"] == "ready" for r in recs):
                 return True
-            if any(s == "error" for s in states):
-                raise RuntimeError(f"stage bring-up failed: {[self.board.read(s) for s in range(self.cfg.pp_size)]}")
+            dead = [i for i, p in enumerate(self.procs) if not p.is_alive()]
+            if any(r["state"] == "error" for r in recs) or dead:
+                raise RuntimeError(f"stage bring-up failed (exited: {dead}): {recs}")
             time.sleep(0.05)
         raise TimeoutError("pipeline stages did not come up")
 
-    def close(self):
-        self.engine.stop()
+    def kill(self):
+        """Replace-don't-repair: SIGKILL every stage process. The driver tears their device contexts
+        and communicators down; nothing in this process waits on a device."""
+        for p in self.procs:
+            if p.is_alive():
+                p.kill()
         for p in self.procs:
             p.join(10.0)
-            if p.is_alive():
-                p.terminate()
-        self.runtime.dump_trace()                  # after the joins: folds in the other stages' files
-        try:
-            import torch.distributed as dist
-            if dist.is_initialized():
-                dist.destroy_process_group()
-        except Exception:
-            pass
-        self.links.close()
+
+    def close(self):
+        fatal = self.engine is not None and self.engine.fatal is not None
+        if self.engine is not None:
+            self.engine.stop()
+        if fatal:
+            self.kill()
+        else:
+            for p in self.procs:
+                p.join(15.0)
+            self.kill()
+        if self.tracer is not None and self.cfg.trace_path:
+            # stage 0 wrote `trace_path` (with the other stages' files folded in): add the scheduler's events
+            try:
+                path = self.cfg.trace_path
+                if os.path.exists(path):
+                    os.replace(path, path + ".stage0")
+                self.tracer.dump(path, merge_glob=path + ".stage*")
+            except Exception:
+                pass
+        for ring in (self.cin, self.res):
+            try:
+                ring.close()
+            except Exception:
+                pass
         self.board.close()
 
 
@@ -287,10 +374,8 @@ def attach_distributed(cfg: EngineConfig):
 
 
 def make_pipeline(cfg: EngineConfig):
-    """The right pipeline object for `cfg`: in-process for one stage or loopback transport,
-    spawned processes otherwise."""
-    if cfg.pp_size == 1 or cfg.resolved_transport() == "loopback":
+    """The right pipeline object for `cfg`: in-process for the loopback transport (and for one stage
+    unless `isolate` asks for a separate stage process), spawned stage processes otherwise."""
+    if cfg.resolved_transport() == "loopback" and not cfg.isolate:
         return LocalPipeline(cfg)
-    p = SpawnedPipeline(cfg)
-    p.wait_ready()
-    return p
+    return SpawnedPipeline(cfg)

@@ -96,7 +96,12 @@ class StageRuntime:
 
     # ---- helpers ---------------------------------------------------------------------------
     def _graph_decode(self, desc: StepBatch) -> bool:
-        return desc.is_decode and hasattr(self.ex, "decode_step") and not self.debug_top5
+        """Static-buffer (hipGraph) decode: single-token steps over a whole fixed-shape micro-batch.
+        Anything else — a prefill chunk, also one made only of 1-token prompts — runs eagerly and
+        leaves the micro-batch's captured state alone."""
+        ex = self.ex
+        return (desc.is_decode and hasattr(ex, "decode_step") and not self.debug_top5
+                and desc.num_seqs == getattr(ex, "max_batch", desc.num_seqs))
 
     def result_count(self, desc: StepBatch) -> int:
         """Number of token ids the last stage produces for `desc`: a static-buffer decode step
@@ -105,10 +110,8 @@ class StageRuntime:
 
     def fb_buffer(self, mb: int, n: int) -> torch.Tensor:
         """Stage 0: where the fed-back tokens of micro-batch `mb` land."""
-        if hasattr(self.ex, "input_buffer") and self.ex.plan.has_embed:
-            buf = self.ex.input_buffer(mb, n)
-            if buf.numel() == n:
-                return buf
+        if hasattr(self.ex, "input_buffer") and self.ex.plan.has_embed and n == getattr(self.ex, "max_batch", -1):
+            return self.ex.input_buffer(mb, n)      # the static token buffer the decode graph reads
         key = (mb, n)
         b = self._fb_bufs.get(key)
         if b is None:
@@ -280,18 +283,40 @@ class StageRuntime:
         path = stage_trace_path(self.trace_path, self.stage)
         return self.tracer.dump(path, merge_glob=(self.trace_path + ".stage*") if self.stage == 0 else None)
 
-    def drain(self):
+    def drain(self, timeout_s: Optional[float] = None):
+        """Finish what this stage has enqueued. With a deadline the host polls instead of parking in
+        a device synchronise, and a stage that does not come idle in time (a transfer spinning on a
+        peer that died) aborts its hops and raises: nothing here can hang forever."""
         for h in self._send_pending.values():
             try:
                 h.wait()
             except Exception:
                 pass
         self._send_pending.clear()
-        if self.on_gpu:
+        if not self.on_gpu:
+            return
+        if timeout_s is None:
             torch.cuda.synchronize(self.device)
+            return
+        evs = []
+        for s in [self._main_stream, *self._decode_streams]:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            evs.append(ev)
+        t0 = time.perf_counter()
+        while not all(ev.query() for ev in evs):
+            if time.perf_counter() - t0 > timeout_s:
+                self.abort()
+                raise TimeoutError(f"stage {self.stage}: device work did not finish within {timeout_s:.1f}s")
+            time.sleep(0.001)
+
+    def abort(self):
+        """Abandon every hop of this stage (RCCL: ncclCommAbort) without waiting for the device."""
+        self._send_pending.clear()
+        self.links.abort()
 
 
-def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5) -> int:
+def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s: float = 30.0) -> int:
     """Blocking loop of a non-zero stage: descriptors in, steps out, until SHUTDOWN.
     Returns the number of steps executed. Errors are recorded on the status board and re-raised."""
     from .shm import ST_ERROR, ST_READY, ST_STOPPED, RingClosed
@@ -318,10 +343,11 @@ def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5) -> int:
         if board is not None:
             board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
         traceback.print_exc()
+        runtime.abort()                 # a failed stage never waits for its neighbours again
         raise
     finally:
         try:
-            runtime.drain()
+            runtime.drain(timeout_s=drain_timeout_s)
             runtime.dump_trace()
         except Exception:
             pass

@@ -87,13 +87,34 @@ class StatusBoard:
     def beat(self, stage: int, steps: int = 0, tokens: int = 0, busy_ns: int = 0):
         self._L.dlia_board_beat(self._h, stage, steps, tokens, busy_ns)
 
+    def set_kv_blocks(self, stage: int, blocks: int):
+        self._L.dlia_board_set_kv(self._h, stage, int(blocks))
+
+    def agree_kv_blocks(self, stage: int, mine: int, timeout_s: float = 600.0) -> int:
+        """Publishes this stage's KV block budget and returns the minimum over all stages once every
+        stage has published its own: block ids are global to the pipeline, so every cache holds
+        exactly that many."""
+        import time
+        self.set_kv_blocks(stage, mine)
+        t0 = time.time()
+        while True:
+            vals = [self.read(s) for s in range(self.num_stages)]
+            if any(v["state"] == "error" for v in vals):
+                raise RuntimeError("a stage failed during bring-up: " + "; ".join(v["error"] for v in vals if v["error"]))
+            if all(v["kv_blocks"] > 0 for v in vals):
+                return min(v["kv_blocks"] for v in vals)
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("stages did not agree on a KV block count")
+            time.sleep(0.01)
+
     def read(self, stage: int) -> Dict:
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 12)()
         err = C.create_string_buffer(64)
         self._L.dlia_board_read(self._h, stage, out, err, 64)
         return {"state": STATE_NAMES.get(int(out[0]), "?"), "pid": int(out[1]), "age_ms": int(out[2]),
                 "steps": int(out[3]), "tokens": int(out[4]), "busy_ns": int(out[5]),
-                "layers": f"{int(out[6])}-{int(out[7])}", "error": err.value.decode(errors="replace")}
+                "layers": f"{int(out[6])}-{int(out[7])}", "kv_blocks": int(out[8]),
+                "error": err.value.decode(errors="replace")}
 
     def close(self):
         if self._h:

@@ -240,6 +240,9 @@ class ShmControl(Control):
     def put(self, msg):
         self.ring.put(msg, timeout_s=120.0)
 
+    def pending(self) -> int:
+        return self.ring.pending()
+
     def get(self, timeout_s=None):
         return self.ring.get(timeout_s)
 
@@ -288,6 +291,15 @@ class PipelineLinks:
     def is_last(self) -> bool:
         return self.stage == self.num_stages - 1
 
+    def abort(self):
+        """Abandon the data hops without waiting for transfers in flight (a peer is gone)."""
+        for x in (self.prev_data, self.next_data, self.fb_data):
+            if x is not None and hasattr(x, "abort"):
+                try:
+                    x.abort()
+                except Exception:
+                    pass
+
     def close(self):
         for x in (self.prev_data, self.next_data, self.fb_data, self.prev_ctrl, self.next_ctrl):
             if x is not None:
@@ -334,8 +346,61 @@ def _warm_up_edges(edges, rank: int, backend: str):
         torch.cuda.synchronize(dev)
 
 
+def _attach_shm_ctrl(links: PipelineLinks, rank: int, world: int, job: str, slot_bytes: int = 1 << 17):
+    # producer creates, consumer attaches (with retry) — no ordering requirement between them
+    if rank < world - 1:
+        links.next_ctrl = ShmControl(f"{job}_c{rank}", create=True, slot_bytes=slot_bytes)
+    if rank > 0:
+        links.prev_ctrl = ShmControl(f"{job}_c{rank - 1}", create=False, slot_bytes=slot_bytes)
+
+
+def make_rccl_links(rank: int, world: int, job: str, device, ctrl_slot_bytes: int = 1 << 17,
+                    warmup_timeout_s: float = 120.0) -> PipelineLinks:
+    """Native RCCL hops for rank `rank` of a `world`-stage pipeline (one process per GPU).
+
+    `torch.distributed` must be initialised with a CPU backend (gloo): it only carries the
+    communicator ids and barriers, never activations. Rank 0 draws one id per hop and broadcasts
+    them; every hop is a two-rank communicator (sender = rank 0 inside it). Communicator creation
+    blocks until the peer joins, so all ranks open their hops in one global order — the chain from
+    stage 0 upwards, then the feedback hop — in which every rank's next blocking call is matched
+    by a rank that has already finished its own earlier ones. One 4-byte message then crosses every
+    hop (RCCL sets a peer connection up on first use; that must not happen inside a captured
+    graph or at an arbitrary point of the serving loop) and is checked on arrival."""
+    import torch.distributed as dist
+    from . import rccl
+    links = PipelineLinks(rank, world)
+    n_hops = world if world > 1 else 0              # world - 1 forward hops + the feedback hop
+    ids = [rccl.unique_id() for _ in range(n_hops)] if rank == 0 else [None] * n_hops
+    if n_hops:
+        dist.broadcast_object_list(ids, src=0)
+    dev = torch.device(device)
+    opened = []                                      # (edge, src stage, dst stage)
+    for s in range(world - 1):
+        if rank == s:
+            links.next_data = rccl.RcclEdge(ids[s], 2, 0, 1, dev, name=f"{s}->{s + 1}")
+            opened.append((links.next_data, s, s + 1))
+        elif rank == s + 1:
+            links.prev_data = rccl.RcclEdge(ids[s], 2, 1, 0, dev, name=f"{s}->{s + 1}")
+            opened.append((links.prev_data, s, s + 1))
+    if world > 1 and rank in (0, world - 1):
+        last = world - 1
+        links.fb_data = rccl.RcclEdge(ids[last], 2, 0 if rank == last else 1, 1 if rank == last else 0, dev,
+                                      name=f"{last}->0 (tokens)")
+        opened.append((links.fb_data, last, 0))
+    for edge, src, dst in opened:
+        if rank == src:
+            edge.send(torch.full((1,), src + 1, dtype=torch.int32, device=dev)).sync(warmup_timeout_s)
+        else:
+            t = torch.zeros(1, dtype=torch.int32, device=dev)
+            edge.recv(t).sync(warmup_timeout_s)
+            if int(t.item()) != src + 1:
+                raise RuntimeError(f"pipeline hop {edge.name}: warm-up message corrupted ({int(t.item())})")
+    _attach_shm_ctrl(links, rank, world, job, ctrl_slot_bytes)
+    return links
+
+
 def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl: bool = True,
-                    host_staged: bool = False) -> PipelineLinks:
+                    host_staged: bool = False, ctrl_slot_bytes: int = 1 << 17) -> PipelineLinks:
     """Process groups and control rings for rank `rank` of a `world`-stage pipeline.
 
     `torch.distributed` must already be initialised (any backend; sub-groups are created with
@@ -360,11 +425,7 @@ def make_dist_links(rank: int, world: int, backend: str, job: str, use_shm_ctrl:
             links.fb_data = TorchDistEdge(g, world - 1, 0, rank, host_staged)
     _warm_up_edges(edges, rank, backend)
     if use_shm_ctrl:
-        # producer creates, consumer attaches (with retry) — no ordering requirement between them
-        if rank < world - 1:
-            links.next_ctrl = ShmControl(f"{job}_c{rank}", create=True)
-        if rank > 0:
-            links.prev_ctrl = ShmControl(f"{job}_c{rank - 1}", create=False)
+        _attach_shm_ctrl(links, rank, world, job, ctrl_slot_bytes)
     else:
         for s in range(world - 1):
             g = dist.new_group(ranks=[s, s + 1], backend="gloo")

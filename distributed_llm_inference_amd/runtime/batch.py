@@ -27,7 +27,8 @@ KIND_SHUTDOWN = 3    # stop the stage loop
 KIND_PING = 4        # liveness probe, forwarded down the pipe and acknowledged by the last stage
 KIND_BARRIER = 5     # drain all outstanding work, then meet every other stage at a barrier
 
-_MAGIC = 0x444C4941  # "DLIA"
+_MAGIC = 0x444C4942  # "DLIB"
+_HEAD = "<IiiiiiiIi"    # magic, kind, step id, micro-batch, B, tokens (-1: none), table ints, replay, growth entries
 
 
 @dataclass
@@ -48,6 +49,11 @@ class StepBatch:
     # block tables: only for sequences whose table changed since the stage last saw them
     table_slots: List[int] = field(default_factory=list)
     table_blocks: List[List[int]] = field(default_factory=list)
+    # on-demand growth: block_table[grow_slots[i]][grow_pos[i]] = grow_blocks[i] (a sequence that
+    # crossed a 32-token boundary got one more block); applied before the step runs, replay or not
+    grow_slots: List[int] = field(default_factory=list)
+    grow_pos: List[int] = field(default_factory=list)
+    grow_blocks: List[int] = field(default_factory=list)
     # stage-0 input: explicit token ids (prefill, or decode whose token the scheduler knows);
     # None => take the tokens the last stage fed back for this micro-batch
     token_ids: Optional[List[int]] = None
@@ -82,6 +88,8 @@ class StepBatch:
             raise ValueError("token_ids length must equal the number of new tokens")
         if len(self.table_slots) != len(self.table_blocks):
             raise ValueError("table_slots / table_blocks mismatch")
+        if not (len(self.grow_slots) == len(self.grow_pos) == len(self.grow_blocks)):
+            raise ValueError("grow_slots / grow_pos / grow_blocks mismatch")
 
     # ---- wire format ------------------------------------------------------------------
     def to_bytes(self) -> bytes:
@@ -90,21 +98,23 @@ class StepBatch:
         tb_flat: List[int] = []
         for s, blocks in zip(self.table_slots, self.table_blocks):
             tb_flat += [s, len(blocks)] + list(blocks)
-        head = struct.pack("<IiiiiiiI", _MAGIC, self.kind, self.step_id, self.micro_batch, B, ntok,
-                           len(tb_flat), 1 if self.replay else 0)
+        ng = len(self.grow_slots)
+        head = struct.pack(_HEAD, _MAGIC, self.kind, self.step_id, self.micro_batch, B, ntok,
+                           len(tb_flat), 1 if self.replay else 0, ng)
         ints = np.asarray(self.slots + self.q_lens + self.ctx_lens + self.sample + self.top_k +
-                          self.sample_steps + tb_flat + (self.token_ids or []), dtype="<i4")
+                          self.sample_steps + tb_flat + self.grow_slots + self.grow_pos + self.grow_blocks +
+                          (self.token_ids or []), dtype="<i4")
         flts = np.asarray(self.temperature + self.top_p, dtype="<f4")
         seeds = np.asarray(self.seeds, dtype="<i8")
         return head + ints.tobytes() + flts.tobytes() + seeds.tobytes()
 
     @staticmethod
     def from_bytes(buf: bytes) -> "StepBatch":
-        hs = struct.calcsize("<IiiiiiiI")
-        magic, kind, step_id, mb, B, ntok, ntb, replay = struct.unpack_from("<IiiiiiiI", buf, 0)
+        hs = struct.calcsize(_HEAD)
+        magic, kind, step_id, mb, B, ntok, ntb, replay, ng = struct.unpack_from(_HEAD, buf, 0)
         if magic != _MAGIC:
             raise ValueError("bad step descriptor magic")
-        n_int = 6 * B + ntb + max(ntok, 0)
+        n_int = 6 * B + ntb + 3 * ng + max(ntok, 0)
         ints = np.frombuffer(buf, dtype="<i4", count=n_int, offset=hs).tolist()
         off = hs + 4 * n_int
         flts = np.frombuffer(buf, dtype="<f4", count=2 * B, offset=off).tolist()
@@ -118,11 +128,13 @@ class StepBatch:
             table_slots.append(s)
             table_blocks.append(tb[i + 2:i + 2 + n])
             i += 2 + n
-        toks = ints[6 * B + ntb:] if ntok >= 0 else None
+        g0 = 6 * B + ntb
+        grow = [ints[g0 + i * ng:g0 + (i + 1) * ng] for i in range(3)]
+        toks = ints[g0 + 3 * ng:] if ntok >= 0 else None
         return StepBatch(kind=kind, step_id=step_id, micro_batch=mb, slots=f[0], q_lens=f[1], ctx_lens=f[2],
                          sample=f[3], top_k=f[4], sample_steps=f[5], temperature=flts[:B], top_p=flts[B:],
                          seeds=seeds, table_slots=table_slots, table_blocks=table_blocks, token_ids=toks,
-                         replay=bool(replay))
+                         replay=bool(replay), grow_slots=grow[0], grow_pos=grow[1], grow_blocks=grow[2])
 
 
 def control(kind: int, slots: Optional[List[int]] = None, step_id: int = 0) -> StepBatch:

@@ -7,9 +7,12 @@ lock: orchestration.py:234,333,372.)
 
 Scheduling model — continuous batching over `num_micro_batches` fixed-shape micro-batches:
 
-* a request is admitted into a free row of a micro-batch (KV blocks reserved for prompt +
-  max_new_tokens), prefilled in chunks of at most `prefill_chunk` tokens, then joins the
-  micro-batch's decode steps;
+* a request is admitted into a free row of a micro-batch when the KV pool has blocks for its
+  prompt (plus a small watermark), prefilled in chunks of at most `prefill_chunk` tokens, then
+  joins the micro-batch's decode steps; its block table grows one 32-token block at a time as it
+  generates, and when the pool runs dry the youngest sequences of the starved micro-batch are
+  preempted — blocks released, request requeued at the front, prompt + tokens so far prefilled
+  again on re-admission — so the pool is sized from HBM, not from slots x max_seq_len;
 * steady-state decode steps are "replays": the token fed to stage 0 is the one the last stage
   sampled for that row (device-to-device feedback), context lengths and RNG counters advance
   on the device, and up to `max_inflight_steps` steps of a micro-batch are issued before their
@@ -35,10 +38,10 @@ from typing import Deque, Dict, List, Optional
 import torch
 
 from ..config import EngineConfig
-from ..parallel.pipeline import StageRuntime
-from ..parallel.transport import Handle
-from .batch import KIND_RELEASE, KIND_SHUTDOWN, StepBatch, control
+from .batch import KIND_RELEASE, StepBatch, control
+from .head import LocalHead
 from .kv_cache import BlockAllocator, blocks_for
+from ..ops.packing import KV_BLOCK
 from .sampler import SamplingParams
 from .tokenizer import build_prompt
 
@@ -59,7 +62,9 @@ class Request:
     row: int = -1
     slot: int = -1
     blocks: List[int] = field(default_factory=list)
-    prefilled: int = 0                # prompt tokens submitted so far
+    context: List[int] = field(default_factory=list)   # tokens to prefill: prompt (+ output so far after a preemption)
+    preemptions: int = 0
+    prefilled: int = 0                # context tokens submitted so far
     issued_ctx: int = 0               # tokens whose KV the submitted steps (will) have cached
     issued_samples: int = 0           # sampling steps submitted
     output: List[int] = field(default_factory=list)
@@ -80,51 +85,28 @@ class Request:
         return self
 
 
-class _Result:
-    """Tokens of one submitted step, on their way to the host."""
+class _Inflight:
+    """One submitted step: its descriptor, the requests of its rows, and the tokens on their way."""
 
-    def __init__(self, desc: StepBatch, rows: List[Optional[Request]], tokens=None, event=None,
-                 handle: Optional[Handle] = None, host=None, gpu_handle: Optional[Handle] = None):
-        self.desc, self.rows = desc, rows
-        self.tokens, self.event, self.handle, self.host = tokens, event, handle, host
-        self.gpu_handle = gpu_handle         # what the next step of this micro-batch must wait for
+    def __init__(self, desc: StepBatch, rows: List[Optional[Request]], res):
+        self.desc, self.rows, self.res = desc, rows, res
         self.t_submit = time.perf_counter()
 
     def ready(self) -> bool:
-        if self.event is not None:
-            return self.event.query()
-        if self.handle is not None:
-            return self.handle.done()
-        return True
+        return self.res.ready()
 
     def get(self) -> List[int]:
-        if self.event is not None:
-            self.event.synchronize()
-            return self.host.tolist()
-        if self.handle is not None:
-            self.handle.wait()
-        return self.tokens.tolist() if self.tokens is not None else []
-
-
-class _EventHandle(Handle):
-    def __init__(self, event):
-        self.event = event
-
-    def wait(self):
-        torch.cuda.current_stream().wait_event(self.event)
-
-    def done(self) -> bool:
-        return self.event.query()
+        return self.res.get()
 
 
 class _MicroBatch:
     def __init__(self, idx: int, size: int):
         self.idx = idx
         self.rows: List[Optional[Request]] = [None] * size
-        self.inflight: Deque[_Result] = collections.deque()
+        self.inflight: Deque[_Inflight] = collections.deque()
         self.state = "idle"           # idle | steady | draining | prefill
         self.fresh: List[Request] = []    # admitted, prefill not finished
-        self.last_fb: Optional[Handle] = None
+        self.starved = False          # a decode step could not be issued: the KV pool had no block for a row
 
     def live(self) -> List[Request]:
         return [r for r in self.rows if r is not None and r.state == "running"]
@@ -137,13 +119,21 @@ class _MicroBatch:
 
 
 class Engine:
-    def __init__(self, cfg: EngineConfig, runtime: StageRuntime, tokenizer, num_blocks: int,
-                 board=None, tracer=None):
-        self.cfg, self.rt, self.tok = cfg, runtime, tokenizer
-        self.spec = runtime.ex.spec
-        self.links = runtime.links
+    def __init__(self, cfg: EngineConfig, head, tokenizer, num_blocks: int, board=None, tracer=None):
+        """`head`: the scheduler's handle on pipeline stage 0 — a `LocalHead` / `RemoteHead`, or a
+        `StageRuntime` of this process (wrapped in a `LocalHead`). `num_blocks`: KV blocks every
+        stage's cache holds (the minimum over the stages' HBM budgets)."""
+        if not hasattr(head, "submit"):
+            head = LocalHead(head)
+        self.cfg, self.head, self.tok = cfg, head, tokenizer
+        self.rt = getattr(head, "rt", None)
+        self.spec = head.spec
+        self.num_stages = head.num_stages
         self.board, self.tracer = board, tracer
         self.alloc = BlockAllocator(num_blocks)
+        self.max_blocks_per_seq = blocks_for(cfg.max_seq_len)
+        # admission keeps this many blocks free for the growth of the sequences already running
+        self.watermark = min(max(1, num_blocks // 100), max(0, num_blocks - self.max_blocks_per_seq))
         self.mbs = [_MicroBatch(i, cfg.max_batch) for i in range(cfg.num_micro_batches)]
         self.waiting: Deque[Request] = collections.deque()
         self._inbox: Deque[Request] = collections.deque()
@@ -154,12 +144,12 @@ class Engine:
         self._rid = 0
         self._step_id = 0
         self.fatal: Optional[str] = None
-        self.on_gpu = runtime.on_gpu
-        self._res_stream = torch.cuda.Stream(device=runtime.device) if self.on_gpu else None
+        self.on_gpu = head.on_gpu
         self._rr = 0
         # counters for /metrics
         self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
-                      "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0}
+                      "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0,
+                      "preemptions": 0, "kv_blocks_grown": 0}
         self.latencies: Deque[float] = collections.deque(maxlen=4096)     # per-token decode latencies (s)
         self.ttfts: Deque[float] = collections.deque(maxlen=1024)
 
@@ -176,12 +166,8 @@ class Engine:
         if self._thread is not None:
             self._thread.join(timeout)
             self._thread = None
-        try:
-            if self.links.next_ctrl is not None:
-                self.links.next_ctrl.put(control(KIND_SHUTDOWN).to_bytes())
-        except Exception:
-            pass
-        self.rt.drain()
+        if self.fatal is None:
+            self.head.shutdown()          # after a fatal error the stages are replaced, not drained
 
     # ---- public API ------------------------------------------------------------------------
     def submit(self, prompt_ids: List[int], params: Optional[SamplingParams] = None) -> Request:
@@ -194,6 +180,7 @@ class Engine:
         if eos is None:
             eos = self.spec.eos_token_id
         req = Request(rid=rid, prompt_ids=list(prompt_ids), params=params, eos_id=eos)
+        req.context = req.prompt_ids
         req.seed = params.seed if params.seed is not None else (time.time_ns() ^ (rid * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
         if self.fatal:
             self._fail(req, self.fatal)
@@ -272,14 +259,14 @@ class Engine:
 
     def _check_pipeline(self):
         """Watchdog: a stage that died or reported an error fails everything in flight."""
-        if self.board is None or self.links.num_stages == 1:
+        if self.board is None or (self.num_stages == 1 and not self.head.remote):
             return
         now = time.perf_counter()
         if now - getattr(self, "_last_check", 0.0) < 0.25:
             return
         self._last_check = now
         from ..utils.procs import pid_alive
-        for s in range(1, self.links.num_stages):
+        for s in range(0 if self.head.remote else 1, self.num_stages):
             st = self.board.read(s)
             dead = False
             if st["state"] == "error":
@@ -289,7 +276,7 @@ class Engine:
                 dead, why = True, f"stage {s} (pid {st['pid']}) is gone"
             if not dead and any(mb.inflight for mb in self.mbs):
                 oldest = min(r.t_submit for mb in self.mbs for r in mb.inflight)
-                if now - oldest > self.cfg.hop_timeout_s * self.links.num_stages:
+                if now - oldest > self.cfg.hop_timeout_s * self.num_stages:
                     dead, why = True, f"pipeline stalled: no result for {now - oldest:.1f}s"
             if dead:
                 raise EngineError(why)
@@ -326,23 +313,32 @@ class Engine:
 
         if mb.state == "steady":
             live = mb.live()
-            waiting_fits = bool(self.waiting) and (mb.free_rows() + mb.dead_rows() > 0)
+            waiting_fits = bool(self.waiting) and (mb.free_rows() + mb.dead_rows() > 0) and self._could_admit()
             if not live or waiting_fits or mb.dead_rows() * 2 >= max(1, len(live) + mb.dead_rows()):
                 mb.state = "draining"
-            elif len(mb.inflight) < self.cfg.max_inflight_steps and self._budget_left(mb) and self._fb_ready(mb):
-                self._submit_decode(mb, replay=True)
-                return True
+            elif (len(mb.inflight) < self.cfg.max_inflight_steps and self._budget_left(mb)
+                  and self.head.fb_ready(mb.idx)):
+                if self._submit_decode(mb, replay=True):
+                    return True
+                mb.state, mb.starved = "draining", True       # no KV block for a row: recompose
 
         if mb.state == "draining":
             if mb.inflight:
                 return progressed
             self._retire(mb)
-            self._admit(mb)
+            if mb.starved:
+                if not self._make_room(mb):
+                    return progressed          # other micro-batches hold the pool: wait for them
+                mb.starved = False
+            else:
+                self._admit(mb)
             if mb.fresh:
                 mb.state = "prefill"
             elif mb.live():
-                self._submit_decode(mb, replay=False)
-                mb.state = "steady"
+                if self._submit_decode(mb, replay=False):
+                    mb.state = "steady"
+                else:
+                    mb.starved = True
                 return True
             else:
                 mb.state = "idle"
@@ -351,32 +347,30 @@ class Engine:
         if mb.state == "prefill":
             if mb.inflight:
                 return progressed
-            pending = [r for r in mb.fresh if r.prefilled < len(r.prompt_ids) and not r.finished]
+            pending = [r for r in mb.fresh if r.prefilled < len(r.context) and not r.finished]
             if pending:
                 self._submit_prefill(mb, pending)
                 return True
             mb.fresh = []
             if mb.live():
-                self._submit_decode(mb, replay=False)
-                mb.state = "steady"
+                if self._submit_decode(mb, replay=False):
+                    mb.state = "steady"
+                else:
+                    mb.state, mb.starved = "draining", True
             else:
                 mb.state = "draining"
             return True
         return progressed
 
-    def _fb_ready(self, mb: _MicroBatch) -> bool:
-        """On the GPU the next step waits for the fed-back tokens on the stream; on CPU transports
-        that wait would block this thread (and its watchdog), so only submit once they are in."""
-        if self.on_gpu or self.links.num_stages == 1 or mb.last_fb is None:
-            return True
-        return mb.last_fb.done()
-
     def _budget_left(self, mb: _MicroBatch) -> bool:
         """Is there a row that still needs tokens beyond what is already in flight?"""
         for r in mb.live():
-            if r.issued_samples < r.params.max_new_tokens and r.issued_ctx + 1 <= self.cfg.max_seq_len:
+            if self._wants_more(r):
                 return True
         return False
+
+    def _wants_more(self, r: Request) -> bool:
+        return r.issued_samples < r.params.max_new_tokens and r.issued_ctx + 1 <= self.cfg.max_seq_len
 
     def _retire(self, mb: _MicroBatch):
         gone = []
@@ -389,26 +383,97 @@ class Engine:
             self.stats["recompositions"] += 1
             self._dispatch(control(KIND_RELEASE, gone))
 
+    # ---- KV blocks: admission, growth, preemption ----------------------------------------------
+    def _could_admit(self) -> bool:
+        """Would the request at the head of the queue get its blocks right now?"""
+        if not self.waiting:
+            return False
+        need = max(1, blocks_for(len(self.waiting[0].context)))
+        return self.alloc.free - need >= self.watermark or self.alloc.used == 0
+
     def _admit(self, mb: _MicroBatch):
         while self.waiting and mb.free_rows() > 0:
             req = self.waiting[0]
-            total = min(len(req.prompt_ids) + req.params.max_new_tokens, self.cfg.max_seq_len)
-            blocks = self.alloc.take(req.rid, blocks_for(total))
+            need = max(1, blocks_for(len(req.context)))
+            if need > self.max_blocks_per_seq or need > self.alloc.num_blocks:
+                self.waiting.popleft()
+                self._fail(req, "request needs more KV blocks than the cache holds")
+                continue
+            if self.alloc.used > 0 and self.alloc.free - need < self.watermark:
+                break                      # keep room for the running sequences to grow
+            blocks = self.alloc.take(req.rid, need)
             if blocks is None:
-                if self.alloc.used == 0:
-                    self.waiting.popleft()
-                    self._fail(req, "request needs more KV blocks than the cache holds")
-                    continue
                 break                      # wait for running requests to free blocks
             self.waiting.popleft()
             row = mb.rows.index(None)
             req.mb, req.row, req.slot = mb.idx, row, mb.idx * self.cfg.max_batch + row
             req.blocks, req.state = blocks, "prefill"
+            req.prefilled = req.issued_ctx = 0
             mb.rows[row] = req
             mb.fresh.append(req)
             if self.tracer is not None:
                 self.tracer.instant("scheduler", "admit", {"rid": req.rid, "mb": mb.idx, "row": row,
-                                                           "prompt_tokens": len(req.prompt_ids)})
+                                                           "prompt_tokens": len(req.context)})
+
+    def _needs_block(self, r: Request) -> bool:
+        """Will the next decode step of `r` write its K/V beyond the blocks it owns?"""
+        return self._wants_more(r) and r.issued_ctx // KV_BLOCK >= len(r.blocks)
+
+    def _grow(self, mb: _MicroBatch, d: Optional[StepBatch]) -> bool:
+        """One more block for every live row about to cross a block boundary; the new table entries
+        ride on `d`. All or nothing: False (and nothing taken) when the pool cannot serve all."""
+        need = [r for r in mb.live() if self._needs_block(r)]
+        if not need:
+            return True
+        if self.alloc.free < len(need):
+            return False
+        for r in need:
+            blk = self.alloc.take(r.rid, 1)
+            if blk is None:                # cannot happen after the check above; stay consistent anyway
+                return False
+            if d is not None:
+                d.grow_slots.append(r.slot); d.grow_pos.append(len(r.blocks)); d.grow_blocks.append(blk[0])
+            r.blocks.append(blk[0])
+            self.stats["kv_blocks_grown"] += 1
+        return True
+
+    def _preempt(self, mb: _MicroBatch, r: Request):
+        """Give `r`'s blocks back and requeue it at the front; on re-admission its prompt and the
+        tokens generated so far are prefilled again (recompute instead of swapping to the host)."""
+        self.alloc.release(r.rid)
+        self._dispatch(control(KIND_RELEASE, [r.slot]))
+        mb.rows[r.row] = None
+        if r in mb.fresh:
+            mb.fresh.remove(r)
+        r.context = r.prompt_ids + r.output
+        r.blocks, r.state, r.mb, r.row, r.slot = [], "waiting", -1, -1, -1
+        r.prefilled = r.issued_ctx = 0
+        r.issued_samples = len(r.output)
+        r.preemptions += 1
+        self.stats["preemptions"] += 1
+        self.waiting.appendleft(r)
+        if self.tracer is not None:
+            self.tracer.instant("scheduler", "preempt", {"rid": r.rid, "tokens": len(r.output)})
+
+    def _make_room(self, mb: _MicroBatch) -> bool:
+        """A drained micro-batch whose rows could not all grow: preempt its youngest sequences until
+        the rest can. The oldest running request of the whole engine is never the victim, so some
+        request always makes progress. False: nothing can be done from this micro-batch right now."""
+        while True:
+            need = sum(1 for r in mb.live() if self._needs_block(r))
+            if self.alloc.free >= need:
+                return True
+            live = sorted(mb.live(), key=lambda r: r.rid)
+            oldest_anywhere = min((r.rid for m in self.mbs for r in m.live()), default=None)
+            victims = [r for r in live if r.rid != oldest_anywhere]
+            if not victims:
+                only = live[0] if live else None
+                if only is not None and self.alloc.used == len(only.blocks):
+                    self._fail(only, "request needs more KV blocks than the cache holds")
+                    self._retire(mb)
+                    continue
+                return False
+            self._preempt(mb, victims[-1])
 
     # ---- step construction -------------------------------------------------------------------
     def _next_step_id(self) -> int:
@@ -422,27 +487,31 @@ class Engine:
         for r in pending:
             if budget <= 0 or len(d.slots) >= self.cfg.max_batch:
                 break
-            n = min(len(r.prompt_ids) - r.prefilled, budget)
-            last = r.prefilled + n == len(r.prompt_ids)
+            n = min(len(r.context) - r.prefilled, budget)
+            last = r.prefilled + n == len(r.context)
             d.slots.append(r.slot); d.q_lens.append(n); d.ctx_lens.append(r.prefilled)
             d.sample.append(1 if last else 0)
             d.temperature.append(r.params.temperature); d.top_k.append(r.params.top_k); d.top_p.append(r.params.top_p)
-            d.seeds.append(r.seed); d.sample_steps.append(0)
-            d.token_ids += r.prompt_ids[r.prefilled:r.prefilled + n]
+            d.seeds.append(r.seed); d.sample_steps.append(len(r.output))
+            d.token_ids += r.context[r.prefilled:r.prefilled + n]
             if r.prefilled == 0:
                 d.table_slots.append(r.slot); d.table_blocks.append(list(r.blocks))
             r.prefilled += n
             r.issued_ctx = r.prefilled
             if last:
-                r.issued_samples = 1
+                r.issued_samples = len(r.output) + 1
                 rows.append(r)
             budget -= n
         self.stats["prefill_steps"] += 1
         self._submit(mb, d, rows)
 
-    def _submit_decode(self, mb: _MicroBatch, replay: bool):
+    def _submit_decode(self, mb: _MicroBatch, replay: bool) -> bool:
+        """Issues one decode step of `mb`. False (nothing issued) when a row needs a KV block the
+        pool does not have."""
         d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, replay=replay,
                       token_ids=None if replay else [])
+        if not self._grow(mb, d):
+            return False
         rows: List[Optional[Request]] = []
         for i, r in enumerate(mb.rows):
             live = r is not None and r.state == "running"
@@ -462,7 +531,7 @@ class Engine:
                 r.issued_ctx += 1
                 r.issued_samples += 1
             rows.append(r if live else None)
-        if not replay and self.rt._graph_decode(d):
+        if not replay and self.head.graph_decode(d):
             # static-buffer decode wants one token per row, padding rows included
             toks, it = [], iter(d.token_ids)
             for q in d.q_lens:
@@ -470,63 +539,22 @@ class Engine:
             d.token_ids = toks
         self.stats["decode_steps"] += 1
         self._submit(mb, d, rows)
+        return True
 
     def _dispatch(self, d: StepBatch):
-        self.rt.execute(d)
+        self.head.control(d)
 
     def _submit(self, mb: _MicroBatch, d: StepBatch, rows: List[Optional[Request]]):
         d.validate()
         self.stats["steps"] += 1
-        n_res = self.rt.result_count(d)
-        fb_wait = mb.last_fb if d.token_ids is None else None
-        with self.rt.stream_scope(d):      # the stream this step runs on (one per decode micro-batch)
-            if self.on_gpu and getattr(mb, "last_copy", None) is not None:
-                # the previous step's tokens must have left the static buffer before it is rewritten
-                torch.cuda.current_stream().wait_event(mb.last_copy)
-            tokens = self.rt.execute(d, fb_wait)
-            res = None
-            if self.links.num_stages == 1:
-                if self.on_gpu:
-                    host = torch.empty(n_res, dtype=torch.int32).pin_memory() if n_res else torch.empty(0, dtype=torch.int32)
-                    ev = torch.cuda.Event()
-                    done = torch.cuda.Event()
-                    done.record()
-                    with torch.cuda.stream(self._res_stream):
-                        self._res_stream.wait_event(done)
-                        if n_res:
-                            host.copy_(tokens, non_blocking=True)
-                        ev.record()
-                    mb.last_copy = ev
-                    res = _Result(d, rows, event=ev, host=host)
-                else:
-                    res = _Result(d, rows, tokens=tokens)
-            else:
-                buf = self.rt.fb_buffer(mb.idx, n_res)
-                if self.on_gpu:
-                    host = torch.empty(n_res, dtype=torch.int32).pin_memory()
-                    ev, got = torch.cuda.Event(), torch.cuda.Event()
-                    with torch.cuda.stream(self._res_stream):
-                        h = self.links.fb_data.recv(buf) if n_res else None
-                        if h is not None:
-                            h.wait()
-                        got.record()
-                        if n_res:
-                            host.copy_(buf, non_blocking=True)
-                        ev.record()
-                    mb.last_fb = _EventHandle(got)
-                    res = _Result(d, rows, event=ev, host=host)
-                else:
-                    h = self.links.fb_data.recv(buf) if n_res else None
-                    mb.last_fb = h
-                    res = _Result(d, rows, tokens=buf, handle=h)
-        mb.inflight.append(res)
+        mb.inflight.append(_Inflight(d, rows, self.head.submit(d)))
 
     # ---- results -------------------------------------------------------------------------------
-    def _harvest(self, mb: _MicroBatch, res: _Result):
+    def _harvest(self, mb: _MicroBatch, res: _Inflight):
         toks = res.get()
         now = time.perf_counter()
         d = res.desc
-        per_row = self.rt._graph_decode(d)
+        per_row = self.head.graph_decode(d)
         k = 0
         for i, r in enumerate(res.rows):
             if per_row:
@@ -543,8 +571,9 @@ class Engine:
     def _on_token(self, r: Request, tok: int, now: float):
         if r.state == "prefill":
             r.state = "running"
-            r.t_first = now
-            self.ttfts.append(now - r.t_arrival)
+            if not r.t_first:               # (a re-prefill after a preemption keeps the first arrival)
+                r.t_first = now
+                self.ttfts.append(now - r.t_arrival)
         elif r.token_times:
             self.latencies.append(now - r.token_times[-1])
         if r.params.stop_on_eos and r.eos_id is not None and tok == r.eos_id:

@@ -1,0 +1,312 @@
+"""The scheduler's view of pipeline stage 0.
+
+The scheduler (`Engine`) only ever does three things with the pipeline: submit a step descriptor
+and later read the token ids it produced, send a control descriptor (release slots, barrier,
+shutdown), and ask how a descriptor will be executed (static-buffer decode or eager). `LocalHead`
+does that on a `StageRuntime` living in the scheduler's process — the stage-0 compute, the token
+feedback receive and the device-to-host copy of the tokens are enqueued here. `RemoteHead` does it
+over two shared-memory rings to a stage-0 process (`head_main`), so that the process that owns the
+HTTP server and the scheduler holds no GPU context at all: when a stage hangs inside a device
+call, the orchestrator stays responsive, answers with the error envelope and replaces every stage
+process. (The reference's orchestrator is such a GPU-less process too, but its failure handling
+is an exception string: orchestration.py:118-122,220-228.)
+"""
+from __future__ import annotations
+
+import queue
+import struct
+import threading
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ..parallel.transport import Handle
+from .batch import KIND_SHUTDOWN, KIND_STEP, StepBatch, control
+
+_RES_MAGIC = 0x52455331      # "RES1"
+
+
+class StepResult:
+    """Token ids of one submitted step, on their way to the scheduler."""
+
+    def __init__(self, tokens=None, event=None, handle: Optional[Handle] = None, host=None):
+        self.tokens, self.event, self.handle, self.host = tokens, event, handle, host
+        self.t_submit = time.perf_counter()
+
+    def ready(self) -> bool:
+        if self.event is not None:
+            return self.event.query()
+        if self.handle is not None:
+            return self.handle.done()
+        return True
+
+    def get(self) -> List[int]:
+        if self.event is not None:
+            self.event.synchronize()
+            return self.host.tolist()
+        if self.handle is not None:
+            self.handle.wait()
+        return self.tokens.tolist() if self.tokens is not None else []
+
+
+class _EventHandle(Handle):
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+    def done(self) -> bool:
+        return self.event.query()
+
+
+class LocalHead:
+    """Stage 0 in this process."""
+
+    remote = False
+
+    def __init__(self, runtime):
+        self.rt = runtime
+        self.links = runtime.links
+        self.spec = runtime.ex.spec
+        self.num_stages = runtime.links.num_stages
+        self.on_gpu = runtime.on_gpu
+        self._res_stream = torch.cuda.Stream(device=runtime.device) if self.on_gpu else None
+        self._last_fb: Dict[int, Handle] = {}        # micro-batch -> arrival of its latest fed-back tokens
+        self._last_copy: Dict[int, object] = {}      # micro-batch -> event: its tokens have left the static buffer
+
+    # ---- how a descriptor will run ----------------------------------------------------------
+    def graph_decode(self, desc: StepBatch) -> bool:
+        return self.rt._graph_decode(desc)
+
+    def result_count(self, desc: StepBatch) -> int:
+        return self.rt.result_count(desc)
+
+    def fb_ready(self, mb: int) -> bool:
+        """On the GPU the next step waits for the fed-back tokens on its stream; on CPU transports
+        that wait would block the calling thread, so a replay step is only submitted once they
+        have arrived."""
+        h = self._last_fb.get(mb)
+        if self.on_gpu or self.num_stages == 1 or h is None:
+            return True
+        return h.done()
+
+    # ---- submission ----------------------------------------------------------------------------
+    def control(self, desc: StepBatch):
+        self.rt.execute(desc)
+
+    def submit(self, d: StepBatch) -> StepResult:
+        rt, mb = self.rt, d.micro_batch
+        n_res = rt.result_count(d)
+        fb_wait = self._last_fb.get(mb) if d.token_ids is None else None
+        with rt.stream_scope(d):           # the stream this step runs on (one per decode micro-batch)
+            last_copy = self._last_copy.get(mb)
+            if self.on_gpu and last_copy is not None:
+                # the previous step's tokens must have left the static buffer before it is rewritten
+                torch.cuda.current_stream().wait_event(last_copy)
+            tokens = rt.execute(d, fb_wait)
+            if self.num_stages == 1:
+                if not self.on_gpu:
+                    return StepResult(tokens=tokens)
+                host = torch.empty(n_res, dtype=torch.int32).pin_memory() if n_res else torch.empty(0, dtype=torch.int32)
+                ev, done = torch.cuda.Event(), torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(self._res_stream):
+                    self._res_stream.wait_event(done)
+                    if n_res:
+                        host.copy_(tokens, non_blocking=True)
+                    ev.record()
+                self._last_copy[mb] = ev
+                return StepResult(event=ev, host=host)
+            buf = rt.fb_buffer(mb, n_res)
+            if self.on_gpu:
+                host = torch.empty(n_res, dtype=torch.int32).pin_memory()
+                ev, got = torch.cuda.Event(), torch.cuda.Event()
+                with torch.cuda.stream(self._res_stream):
+                    h = self.links.fb_data.recv(buf) if n_res else None
+                    if h is not None:
+                        h.wait()
+                    got.record()
+                    if n_res:
+                        host.copy_(buf, non_blocking=True)
+                    ev.record()
+                self._last_fb[mb] = _EventHandle(got)
+                return StepResult(event=ev, host=host)
+            h = self.links.fb_data.recv(buf) if n_res else None
+            self._last_fb[mb] = h
+            return StepResult(tokens=buf, handle=h)
+
+    def shutdown(self):
+        try:
+            if self.links.next_ctrl is not None:
+                self.links.next_ctrl.put(control(KIND_SHUTDOWN).to_bytes())
+        except Exception:
+            pass
+        self.rt.drain()
+
+
+# ---------------------------------------------------------------------------------------------
+def pack_result(step_id: int, tokens: List[int], error: str = "") -> bytes:
+    err = error.encode()[:2048]
+    head = struct.pack("<IiiI", _RES_MAGIC, step_id, len(tokens), len(err))
+    return head + np.asarray(tokens, dtype="<i4").tobytes() + err
+
+
+def unpack_result(buf: bytes):
+    magic, step_id, n, nerr = struct.unpack_from("<IiiI", buf, 0)
+    if magic != _RES_MAGIC:
+        raise ValueError("bad result message")
+    off = struct.calcsize("<IiiI")
+    toks = np.frombuffer(buf, dtype="<i4", count=n, offset=off).tolist()
+    err = bytes(buf[off + 4 * n: off + 4 * n + nerr]).decode(errors="replace")
+    return step_id, toks, err
+
+
+class _RemoteResult:
+    def __init__(self, head: "RemoteHead", step_id: int):
+        self.head, self.step_id = head, step_id
+        self.t_submit = time.perf_counter()
+
+    def ready(self) -> bool:
+        self.head._pump()
+        return self.step_id in self.head._arrived
+
+    def get(self) -> List[int]:
+        t0 = time.perf_counter()
+        while not self.ready():
+            if time.perf_counter() - t0 > self.head.timeout_s:
+                raise TimeoutError(f"no result for step {self.step_id} from stage 0")
+            time.sleep(50e-6)
+        toks, err = self.head._arrived.pop(self.step_id)
+        if err:
+            raise RuntimeError(f"stage 0: {err}")
+        return toks
+
+
+class RemoteHead:
+    """Stage 0 in another process: descriptors out over `cin`, token ids back over `res`."""
+
+    remote = True
+    on_gpu = False          # nothing in this process touches a device
+
+    def __init__(self, spec, num_stages: int, cin, res, graph_capable: bool, graph_rows: int,
+                 debug_top5: bool = False, timeout_s: float = 60.0):
+        """`graph_capable` / `graph_rows`: whether the stages run fixed-shape decode steps over static
+        buffers (HIP executor) and the row count of such a step — the same rule the stages apply
+        (`StageRuntime._graph_decode`), needed here to know how many token ids a step returns."""
+        self.spec, self.num_stages = spec, num_stages
+        self.cin, self.res = cin, res
+        self.graph_capable = graph_capable and not debug_top5
+        self.graph_rows = graph_rows
+        self.timeout_s = timeout_s
+        self._arrived: Dict[int, tuple] = {}
+
+    def graph_decode(self, desc: StepBatch) -> bool:
+        return self.graph_capable and desc.is_decode and desc.num_seqs == self.graph_rows
+
+    def result_count(self, desc: StepBatch) -> int:
+        return desc.num_seqs if self.graph_decode(desc) else desc.num_samples
+
+    def fb_ready(self, mb: int) -> bool:
+        return True
+
+    def _pump(self):
+        while self.res.pending() > 0:
+            msg = self.res.get(timeout_s=0.0)
+            if msg is None:
+                return
+            step_id, toks, err = unpack_result(msg)
+            if step_id < 0 and err:        # the stage-0 loop itself failed
+                raise RuntimeError(f"stage 0: {err}")
+            self._arrived[step_id] = (toks, err)
+
+    def control(self, desc: StepBatch):
+        self.cin.put(desc.to_bytes())
+
+    def submit(self, d: StepBatch) -> _RemoteResult:
+        self.cin.put(d.to_bytes())
+        return _RemoteResult(self, d.step_id)
+
+    def shutdown(self):
+        try:
+            self.cin.put(control(KIND_SHUTDOWN).to_bytes())
+        except Exception:
+            pass
+
+
+def head_main(runtime, cin, res, idle_beat_s: float = 0.5) -> int:
+    """Loop of a stage-0 process serving a `RemoteHead`: descriptors in, token ids out, until
+    SHUTDOWN. A forwarder thread waits for each step's tokens (device event / feedback receive) in
+    submission order, so the descriptor loop itself never blocks on the device."""
+    from ..parallel.shm import ST_ERROR, ST_READY, ST_STOPPED, RingClosed
+    head = LocalHead(runtime)
+    board = runtime.board
+    pending: "queue.Queue" = queue.Queue()
+    failed = threading.Event()
+    res_lock = threading.Lock()          # the ring is single-producer: forwarder and error path take turns
+
+    def reply(msg: bytes):
+        with res_lock:
+            res.put(msg)
+
+    def forward():
+        while True:
+            item = pending.get()
+            if item is None:
+                return
+            step_id, r = item
+            try:
+                reply(pack_result(step_id, r.get()))
+            except BaseException as e:          # reported to the scheduler, which fails the requests
+                failed.set()
+                if board is not None:
+                    board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
+                try:
+                    reply(pack_result(step_id, [], f"{type(e).__name__}: {e}"))
+                except Exception:
+                    pass
+                return
+
+    th = threading.Thread(target=forward, name="dlia-head-results", daemon=True)
+    th.start()
+    if board is not None:
+        board.set_state(runtime.stage, ST_READY)
+    try:
+        while not failed.is_set():
+            try:
+                msg = cin.get(timeout_s=idle_beat_s)
+            except RingClosed:
+                break
+            if msg is None:
+                if board is not None:
+                    board.beat(runtime.stage)
+                continue
+            desc = StepBatch.from_bytes(msg)
+            if desc.kind == KIND_SHUTDOWN:
+                head.shutdown()
+                break
+            if desc.kind == KIND_STEP:
+                pending.put((desc.step_id, head.submit(desc)))
+            else:
+                head.control(desc)
+    except BaseException as e:
+        if board is not None:
+            board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
+        try:
+            reply(pack_result(-1, [], f"{type(e).__name__}: {e}"))
+        except Exception:
+            pass
+        runtime.abort()
+        raise
+    finally:
+        pending.put(None)
+        th.join(5.0)
+        try:
+            runtime.dump_trace()
+        except Exception:
+            pass
+    if board is not None and not failed.is_set():
+        board.set_state(runtime.stage, ST_STOPPED)
+    return runtime.steps

@@ -12,7 +12,11 @@ from __future__ import annotations
 import argparse
 import dataclasses
 import json
+import os
 import sys
+
+# more HIP streams than HIP's default 4 hardware queues per process: see bench.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from ..config import EngineConfig
 
@@ -27,7 +31,12 @@ def _add_engine_args(ap):
     ap.add_argument("--layer-ranges", help='explicit ranges, e.g. "0-11,11-22"')
     ap.add_argument("--backend", choices=["auto", "hip", "torch"])
     ap.add_argument("--device", choices=["auto", "cuda", "cpu"])
-    ap.add_argument("--transport", choices=["auto", "rccl", "gloo", "loopback", "http"])
+    ap.add_argument("--transport", choices=["auto", "rccl", "rccl-torch", "gloo", "loopback", "http"],
+                    help="rccl: native ncclSend/ncclRecv hops over xGMI (default on GPUs); rccl-torch: torch.distributed p2p")
+    ap.add_argument("--isolate", action="store_true",
+                    help="run every stage (also a single one) in its own process: the serving process then holds no GPU context")
+    ap.add_argument("--kv-mem-fraction", type=float, help="share of free device memory the KV cache takes (default 0.85)")
+    ap.add_argument("--server", choices=["uvicorn", "flask"], help="HTTP server for `serve` (default uvicorn)")
     ap.add_argument("--max-batch", type=int)
     ap.add_argument("--num-micro-batches", type=int)
     ap.add_argument("--max-seq-len", type=int)
@@ -50,7 +59,7 @@ def config_from_args(a) -> EngineConfig:
     base = EngineConfig.from_env(EngineConfig.from_dict(base)).to_dict()
     for k in ("model", "dtype", "kv_dtype", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
               "max_seq_len", "prefill_chunk", "kv_blocks", "max_tokens_cap", "host", "port", "seed", "fault_inject",
-              "trace_path"):
+              "trace_path", "kv_mem_fraction", "server"):
         v = getattr(a, k, None)
         if v is not None:
             base[k] = v
@@ -64,6 +73,8 @@ def config_from_args(a) -> EngineConfig:
         base["debug_top5"] = True
     if getattr(a, "auto_restart", False):
         base["auto_restart"] = True
+    if getattr(a, "isolate", False):
+        base["isolate"] = True
     if getattr(a, "pp_size", None) is not None and getattr(a, "num_micro_batches", None) is None:
         base["num_micro_batches"] = 0
     return EngineConfig.from_dict(base)

@@ -34,6 +34,7 @@ def lib():
             "dlia_board_register": (None, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
             "dlia_board_set_state": (None, [vp, C.c_int, C.c_int, cp]),
             "dlia_board_beat": (None, [vp, C.c_int, i64, i64, i64]),
+            "dlia_board_set_kv": (None, [vp, C.c_int, i64]),
             "dlia_board_read": (None, [vp, C.c_int, C.POINTER(i64), cp, C.c_int]),
             "dlia_board_close": (None, [vp, C.c_int]),
             "dlia_alloc_create": (vp, [i32]),
