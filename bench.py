@@ -134,7 +134,8 @@ class Driver:
         B = self.B
         for mb in range(self.nmb):
             if first:
-                d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, [(7 * (mb * B + i)) % 1000 + 10 for i in range(B)])
+                span = max(1, min(1000, self.rt.ex.spec.vocab_size - 20))
+                d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, [(7 * (mb * B + i)) % span + 10 for i in range(B)])
                 fbw = None
             else:
                 d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, None, replay=True)

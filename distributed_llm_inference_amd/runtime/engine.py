@@ -146,6 +146,13 @@ class Engine:
         self.fatal: Optional[str] = None
         self.on_gpu = head.on_gpu
         self._rr = 0
+        # Fixed-shape decode (static buffers, hipGraph) keeps computing a finished row as padding and
+        # feeds every row's token back on the device; an eager executor feeds back one token per
+        # LIVE row, so there a replay step is only valid while the set of live rows is unchanged.
+        B = cfg.max_batch
+        probe = StepBatch(slots=list(range(B)), q_lens=[1] * B, ctx_lens=[0] * B, sample=[1] * B, temperature=[0.0] * B,
+                          top_k=[1] * B, top_p=[1.0] * B, seeds=[0] * B, sample_steps=[0] * B)
+        self._static_decode = bool(head.graph_decode(probe))
         # counters for /metrics
         self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
                       "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0,
@@ -314,7 +321,8 @@ class Engine:
         if mb.state == "steady":
             live = mb.live()
             waiting_fits = bool(self.waiting) and (mb.free_rows() + mb.dead_rows() > 0) and self._could_admit()
-            if not live or waiting_fits or mb.dead_rows() * 2 >= max(1, len(live) + mb.dead_rows()):
+            if (not live or waiting_fits or mb.dead_rows() * 2 >= max(1, len(live) + mb.dead_rows())
+                    or (mb.dead_rows() > 0 and not self._static_decode)):
                 mb.state = "draining"
             elif (len(mb.inflight) < self.cfg.max_inflight_steps and self._budget_left(mb)
                   and self.head.fb_ready(mb.idx)):

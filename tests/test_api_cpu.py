@@ -235,6 +235,48 @@ def test_auto_restart_rebuilds_the_pipeline_after_a_stage_died():
         b.close()
 
 
+def test_a_stage_that_hangs_forever_fails_the_request_in_time_and_is_replaced():
+    """A stage stuck inside a call that never returns (here: a sleep of an hour; on a GPU: a receive
+    spinning on a dead peer). The serving process holds no stage itself, so its watchdog answers the
+    request with the error envelope within hop_timeout_s x stages, /workers shows the pipeline is
+    not healthy, and the next request runs on freshly spawned stage processes (the hung one is
+    killed, not drained). Parity: orchestration.py:118-122,220-228,306-329."""
+    pipe = make_pipeline(cfg(pp_size=2, partition="even", transport="gloo", fault_inject="stage1:stall@3:3600",
+                             hop_timeout_s=2, auto_restart=True))
+    b = EngineBackend(pipe)
+    try:
+        old_pids = [p.pid for p in pipe.procs]
+        t0 = time.time()
+        first = b.generate("Hello", 20, 0.0)
+        took = time.time() - t0
+        assert first["status"] == "failed" and first["error"].startswith("Error: ")
+        assert took < 2 * 2 + 10, took                    # hop_timeout_s x P, plus scheduling slack
+        second = b.generate("Hello", 6, 0.0)
+        assert second["status"] == "success" and second["tokens_generated"] == 6, second
+        assert b.restarts == 1 and b.workers() == {"worker_1": "online", "worker_2": "online"}
+        from distributed_llm_inference_amd.utils.procs import pid_alive
+        assert not any(pid_alive(p) for p in old_pids)    # the hung stage did not survive the restart
+    finally:
+        b.close()
+
+
+def test_single_stage_can_run_in_its_own_process():
+    """`isolate`: even one stage lives in a child process; the scheduler's process reaches it over
+    the descriptor and result rings only."""
+    pipe = make_pipeline(cfg(isolate=True))
+    try:
+        assert len(pipe.procs) == 1 and pipe.engine.head.remote
+        out = pipe.engine.generate_text("Hello", max_new_tokens=5, temperature=0.0)
+        assert out["status"] == "success" and out["tokens_generated"] == 5
+        ref = LocalPipeline(cfg())
+        try:
+            assert ref.engine.generate_text("Hello", max_new_tokens=5, temperature=0.0)["response"] == out["response"]
+        finally:
+            ref.close()
+    finally:
+        pipe.close()
+
+
 def test_injected_exception_on_a_thread_stage_is_reported():
     pipe = LocalPipeline(cfg(pp_size=2, partition="even", fault_inject="stage1:raise@2", hop_timeout_s=2))
     try:

@@ -69,6 +69,22 @@ def test_two_ranks_under_torch_distributed_run():
     assert r["config"]["micro_batches"] == 4 and len(r["config"]["layer_ranges"]) == 2
 
 
+def test_eight_ranks_under_torch_distributed_run():
+    """The driver's N = 8 launch line, rehearsed on CPU: eight stage processes, seven forward hops
+    and the token feedback hop over gloo, 16 micro-batches in flight, rank 0 prints the one line."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--cpu", "--gpus", "8",
+                        "--model", "tiny-llama-8l-test", "--steps", "3", "--warmup", "1", "--batch", "4",
+                        "--max-seconds", "400"],
+                       capture_output=True, text=True, timeout=450, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    r = _check(lines[0], 8, 3, 1)
+    assert r["config"]["micro_batches"] == 16 and len(r["config"]["layer_ranges"]) == 8
+
+
 def test_micro_batch_shrinks_when_the_kv_cache_would_not_fit(monkeypatch):
     spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
     b = importlib.util.module_from_spec(spec)

@@ -235,3 +235,73 @@ def test_trace_file_has_step_and_scheduler_events(tmp_path):
     names = {e["name"] for e in ev}
     assert {"enqueue step", "admit", "finish"} <= names
     assert all(e["dur"] >= 0 for e in ev if e["ph"] == "X")
+
+
+# ---- KV blocks on demand ----------------------------------------------------------------------
+def test_kv_blocks_grow_on_demand_and_many_more_requests_than_the_pool_holds_all_complete():
+    """The pool is a quarter of slots x max_seq_len; sequences get one block per 32 tokens as they
+    generate; 10x more requests than slots all complete with the tokens of an unconstrained engine."""
+    ps = prompts(80, seed=31)
+    roomy = LocalPipeline(cfg(max_seq_len=256))
+    try:
+        want = run(roomy, ps, greedy(40))
+    finally:
+        roomy.close()
+    # 8 slots x 256 tokens = 64 blocks at full length; give the pool 16
+    pipe = LocalPipeline(cfg(max_seq_len=256, kv_blocks=16))
+    try:
+        got = run(pipe, ps, greedy(40))
+        snap = pipe.engine.snapshot()
+    finally:
+        pipe.close()
+    assert got == want
+    assert snap["failed"] == 0 and snap["completed"] == 80 and snap["fatal"] is None
+    assert snap["kv_blocks_total"] == 16 and snap["kv_blocks_grown"] > 0
+    assert snap["kv_blocks_used"] == 0                      # everything was given back
+
+
+def test_preemption_recomputes_and_keeps_the_tokens_identical():
+    """A pool too small for all running sequences to finish: the youngest are preempted (blocks
+    released, prompt + generated tokens prefilled again later) and still produce exactly the tokens
+    of an engine that never ran out."""
+    ps = [p * 2 for p in prompts(8, seed=5)]                # 6..78 tokens
+    roomy = LocalPipeline(cfg(max_seq_len=256, num_micro_batches=1, max_batch=8))
+    try:
+        want = run(roomy, ps, greedy(70))
+    finally:
+        roomy.close()
+    need_all = sum((len(p) + 70 + 31) // 32 for p in ps)
+    pipe = LocalPipeline(cfg(max_seq_len=256, num_micro_batches=1, max_batch=8, kv_blocks=max(6, need_all // 2)))
+    try:
+        got = run(pipe, ps, greedy(70))
+        snap = pipe.engine.snapshot()
+    finally:
+        pipe.close()
+    assert got == want
+    assert snap["preemptions"] > 0 and snap["failed"] == 0 and snap["kv_blocks_used"] == 0
+
+
+def test_a_request_larger_than_the_whole_pool_fails_cleanly_and_others_continue():
+    pipe = LocalPipeline(cfg(max_seq_len=256, kv_blocks=3))
+    try:
+        big = pipe.engine.submit(list(range(3, 3 + 120)), greedy(4))       # 4 blocks of prompt > 3
+        ok = pipe.engine.submit([5, 6, 7], greedy(4))
+        assert big.wait(30).state == "failed" and "KV blocks" in big.error
+        assert len(ok.wait(30).output) == 4
+        grows = pipe.engine.submit([9] * 30, greedy(80))                   # outgrows the pool while alone
+        assert grows.wait(60).state == "failed" and "KV blocks" in grows.error
+        assert len(pipe.engine.submit([5, 6, 7], greedy(4)).wait(30).output) == 4
+    finally:
+        pipe.close()
+
+
+def test_descriptor_ring_slots_are_sized_from_the_configuration():
+    from distributed_llm_inference_amd.parallel.launcher import ctrl_slot_bytes
+    from distributed_llm_inference_amd.runtime.batch import StepBatch
+    c = cfg(max_batch=1024, max_seq_len=32768, prefill_chunk=2048)
+    B = c.max_batch
+    worst = StepBatch(step_id=1, micro_batch=0, slots=list(range(B)), q_lens=[2] * B, ctx_lens=[0] * B, sample=[1] * B,
+                      temperature=[0.7] * B, top_k=[50] * B, top_p=[0.9] * B, seeds=[1] * B, sample_steps=[0] * B,
+                      token_ids=[1] * (2 * B), table_slots=list(range(B)), table_blocks=[[7]] * (B - 1) + [[7] * 1024],
+                      grow_slots=list(range(B)), grow_pos=[1] * B, grow_blocks=[3] * B)
+    assert len(worst.to_bytes()) <= ctrl_slot_bytes(c)

@@ -251,3 +251,85 @@ def test_stale_cache_contents_never_influence_results(kv_dtype):
     clean, dirty = serve(False), serve(True)
     assert all(len(o) == 12 for o in clean)
     assert dirty == clean
+
+
+# ---- KV cache sized from HBM, blocks on demand ------------------------------------------------
+def test_ten_times_more_requests_than_slots_with_a_pool_a_quarter_of_slots_times_max_seq_len():
+    """16 slots x 256 tokens would be 128 blocks; the pool has 32. Every sequence gets blocks as it
+    grows, finished ones hand theirs on, nothing fails, and the tokens are those of a roomy engine."""
+    ps = prompts(160, seed=12)
+    want, _ = run(cfg(), ps, greedy(40), timeout=300)
+    got, snap = run(cfg(kv_blocks=32), ps, greedy(40), timeout=300)
+    assert got == want
+    assert snap["failed"] == 0 and snap["completed"] == 160 and snap["fatal"] is None
+    assert snap["kv_blocks_total"] == 32 and snap["kv_blocks_grown"] > 0 and snap["kv_blocks_used"] == 0
+
+
+def test_preemption_on_the_gpu_keeps_greedy_tokens():
+    ps = [p + p for p in prompts(8, seed=13)]
+    want, _ = run(cfg(num_micro_batches=1), ps, greedy(90), timeout=300)
+    need_all = sum((len(p) + 90 + 31) // 32 for p in ps)
+    got, snap = run(cfg(num_micro_batches=1, kv_blocks=need_all // 2), ps, greedy(90), timeout=300)
+    assert snap["preemptions"] > 0 and snap["failed"] == 0
+    assert got == want
+
+
+def test_kv_mem_fraction_sizes_the_cache_from_free_device_memory():
+    """No kv_blocks given: the cache takes `kv_mem_fraction` of what is free after weights and
+    workspaces. Twice the fraction, about twice the blocks; the scheduler's pool is that size."""
+    sizes = {}
+    for frac in (0.02, 0.04):
+        pipe = LocalPipeline(cfg(max_batch=256, num_micro_batches=4, max_seq_len=32768, kv_mem_fraction=frac))
+        try:
+            ex = pipe.executors[0]
+            rep = ex.memory_report()
+            assert pipe.engine.alloc.num_blocks == ex.num_blocks == rep["kv_blocks"]
+            free, total = torch.cuda.mem_get_info()
+            assert rep["kv_gib"] * 2 ** 30 <= frac * total
+            sizes[frac] = ex.num_blocks
+            out = pipe.engine.submit(list(range(5, 40)), greedy(8)).wait(120).output
+            assert len(out) == 8
+        finally:
+            pipe.close()
+        del pipe, ex
+        torch.cuda.empty_cache()
+    assert sizes[0.04] > 1.5 * sizes[0.02] > 1000, sizes
+
+
+def test_llama3_70b_stage_of_pp8_leaves_over_200_gb_for_its_kv_cache():
+    """One stage of Llama-3-70B split 8 ways (10 layers, 17.6 GB of bf16 weights) on a 288 GB
+    MI355X: the cache sized from the remaining memory holds more than 200 GB (about 5 M tokens)."""
+    from distributed_llm_inference_amd.models.partition import make_plans
+    from distributed_llm_inference_amd.models.spec import ModelSpec
+    from distributed_llm_inference_amd.models.stage_gpu import GpuStage
+    from distributed_llm_inference_amd.models.weights import random_stage_weights
+    spec = ModelSpec.from_pretrained("llama-3-70b")
+    plan = make_plans(spec, 8, mode="even")[3]
+    assert plan.num_layers == 10
+    w = random_stage_weights(spec, plan, seed=0, device="cuda", dtype=torch.bfloat16)
+    ex = GpuStage(spec, plan, w, max_slots=8192, max_seq_len=32768, max_tokens=2048, max_batch=1024,
+                  kv_mem_fraction=0.85, decode_states=2)
+    rep = ex.memory_report()
+    assert rep["weights_gib"] > 15 and rep["kv_gib"] * 2 ** 30 >= 200e9, rep
+    assert rep["kv_tokens"] >= 4_500_000, rep
+    del ex, w
+    torch.cuda.empty_cache()
+
+
+def test_decode_graph_is_captured_once_across_recompositions_on_a_two_stage_pipeline():
+    """Prefill chunks, 1-token prompts and token feedback of odd sizes must not replace a
+    micro-batch's static decode state: after two waves of requests (several recompositions) every
+    stage has captured exactly one graph per micro-batch it served."""
+    c = cfg(pp_size=2, num_micro_batches=2, max_batch=4)
+    pipe = LocalPipeline(c)
+    try:
+        for wave in range(2):
+            ps = prompts(9, seed=20 + wave) + [[7], [9]]            # includes 1-token prompts
+            reqs = [pipe.engine.submit(p, greedy(10)) for p in ps]
+            assert all(len(r.wait(120).output) == 10 for r in reqs)
+        assert pipe.engine.snapshot()["recompositions"] >= 2
+        for ex in pipe.executors:
+            assert 1 <= ex.graph_captures <= c.num_micro_batches, ex.graph_captures
+            assert len(ex._mbs) <= c.num_micro_batches
+    finally:
+        pipe.close()
