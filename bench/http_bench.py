@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Load test of the HTTP front door: N concurrent clients POST /generate to a running orchestrator
+(`python -m distributed_llm_inference_amd serve ...`) or to one this script starts, and the script
+reports requests/s, output tokens/s and p50 / p99 request latency — the path the reference serves
+from Flask's development server (orchestration.py:331-372), measured end to end through HTTP.
+
+    python bench/http_bench.py --spawn --model llama-3-8b --clients 256 --requests 2048 --max-tokens 32
+    python bench/http_bench.py --url http://127.0.0.1:5000 --clients 64 --requests 512
+"""
+import argparse
+import asyncio
+import json
+import os
+import signal
+import socket
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+async def run_load(url, clients, requests, max_tokens, prompt_words, timeout):
+    import httpx
+    lat, toks, fails = [], 0, 0
+    sem = asyncio.Semaphore(clients)
+    limits = httpx.Limits(max_connections=clients, max_keepalive_connections=clients)
+    async with httpx.AsyncClient(limits=limits, timeout=timeout) as cl:
+        async def one(i):
+            nonlocal toks, fails
+            body = {"prompt": " ".join(f"w{(i * 7 + k) % 997}" for k in range(prompt_words)), "max_tokens": max_tokens,
+                    "temperature": 0.7}
+            async with sem:
+                t0 = time.perf_counter()
+                try:
+                    r = await cl.post(url + "/generate", json=body)
+                    d = r.json()
+                    if r.status_code == 200 and d.get("status") == "success":
+                        toks += int(d["tokens_generated"])
+                        lat.append(time.perf_counter() - t0)
+                    else:
+                        fails += 1
+                except Exception:
+                    fails += 1
+        t0 = time.perf_counter()
+        await asyncio.gather(*(one(i) for i in range(requests)))
+        wall = time.perf_counter() - t0
+    lat.sort()
+    pick = lambda q: round(lat[min(len(lat) - 1, int(q * len(lat)))] * 1e3, 1) if lat else None
+    return {"requests": requests, "clients": clients, "failed": fails, "wall_s": round(wall, 3),
+            "requests_per_s": round((requests - fails) / wall, 2), "output_tokens_per_s": round(toks / wall, 1),
+            "latency_ms_p50": pick(0.5), "latency_ms_p99": pick(0.99), "max_tokens": max_tokens}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--url")
+    ap.add_argument("--spawn", action="store_true", help="start an orchestrator on a free port for the run")
+    ap.add_argument("--server", default="uvicorn", choices=["uvicorn", "flask"])
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--device", default="auto")
+    ap.add_argument("--pp-size", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--micro-batches", type=int, default=2)
+    ap.add_argument("--max-seq-len", type=int, default=1024)
+    ap.add_argument("--clients", type=int, default=256)
+    ap.add_argument("--requests", type=int, default=1024)
+    ap.add_argument("--max-tokens", type=int, default=32)
+    ap.add_argument("--prompt-words", type=int, default=16)
+    ap.add_argument("--timeout", type=float, default=600.0)
+    a = ap.parse_args()
+    proc = None
+    url = a.url
+    if a.spawn or not url:
+        port = free_port()
+        url = f"http://127.0.0.1:{port}"
+        cmd = [sys.executable, "-m", "distributed_llm_inference_amd", "serve", "--model", a.model, "--dtype", a.dtype,
+               "--device", a.device, "--pp-size", str(a.pp_size), "--max-batch", str(a.batch),
+               "--num-micro-batches", str(a.micro_batches), "--max-seq-len", str(a.max_seq_len),
+               "--max-tokens-cap", str(max(a.max_tokens, 32)), "--host", "127.0.0.1", "--port", str(port),
+               "--server", a.server]
+        proc = subprocess.Popen(cmd, cwd=ROOT, start_new_session=True)
+        import httpx
+        t0 = time.time()
+        while True:
+            try:
+                if httpx.get(url + "/health", timeout=2).status_code == 200:
+                    break
+            except Exception:
+                pass
+            if proc.poll() is not None or time.time() - t0 > 900:
+                raise SystemExit("orchestrator did not come up")
+            time.sleep(0.5)
+    try:
+        asyncio.run(run_load(url, min(a.clients, 8), min(a.requests, 16), a.max_tokens, a.prompt_words, a.timeout))   # warm-up
+        out = asyncio.run(run_load(url, a.clients, a.requests, a.max_tokens, a.prompt_words, a.timeout))
+        out.update({"server": a.server if proc else "external", "model": a.model, "dtype": a.dtype, "pp_size": a.pp_size,
+                    "micro_batch": a.batch, "micro_batches": a.micro_batches})
+        print(json.dumps(out))
+    finally:
+        if proc is not None:
+            os.killpg(proc.pid, signal.SIGTERM)
+            try:
+                proc.wait(30)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+
+
+if __name__ == "__main__":
+    main()

@@ -155,6 +155,7 @@ class GpuStage:
                 if e_ == 6 or sk > 1:               # direct epilogues of an unsplit GEMM need no partials
                     need = max(need, sk * m_ * n_)
         self._ws_floats = need
+        self._gemm_shapes = [(spec.qkv_size, H), (H, spec.q_size), (H, I), (2 * I if spec.is_llama else I, H)]
         self.wk0 = self._new_work(self.max_tokens)
         # eager-path metadata (device) + pinned staging
         i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
@@ -181,9 +182,17 @@ class GpuStage:
         s, dev, bf = self.spec, self.device, torch.bfloat16
         z = lambda *shape, dt=bf: torch.zeros(*shape, device=dev, dtype=dt)
         B = self.max_batch
+        # GEMM workspace: split-K partials of the weight-streaming kernels (up to DECODE_ROWS rows) in
+        # front, or the slabs of the large-M kernel's in-launch split-K; the last 4096 words are that
+        # kernel's arrival counters and must stay zero between launches (nobody else writes there)
+        ws_floats = self._ws_floats
+        if self.wmode == "bf16":
+            for m_ in {rows, min(rows, 512), min(rows, 1024)}:
+                if m_ > DECODE_ROWS:
+                    ws_floats = max([ws_floats] + [int(self.K.gemm_ws_floats(m_, n_, k_)) for n_, k_ in self._gemm_shapes])
         return _Work(
             h=z(rows, s.hidden_size), xn=z(rows, s.hidden_size), qkv=z(rows, s.qkv_size), attn=z(rows, s.q_size),
-            act=z(rows, s.intermediate_size), ws=z(self._ws_floats, dt=torch.float32),
+            act=z(rows, s.intermediate_size), ws=z(ws_floats + 4096, dt=torch.float32),
             attn_ws=z(int(self.K.attention_ws_floats(B, 1, s.num_heads, s.num_kv_heads, s.head_dim, self.max_splits)),
                       dt=torch.float32),
             xq=z(rows, max(s.hidden_size, s.q_size, s.intermediate_size), dt=torch.uint8) if self.wmode == "fp8" else None,
@@ -333,20 +342,23 @@ class GpuStage:
             return xn
 
         if T > DECODE_ROWS:
-            # prefill regime: tiled MFMA GEMMs with fused bias / residual / activation epilogues
+            # compute-bound regime (large decode micro-batches, prefill chunks): tiled MFMA GEMMs with
+            # fused bias / residual / activation epilogues; the bf16 kernel splits K inside the launch
+            # on shapes with fewer tiles than CUs and needs the workspace for that
+            lws = wk.ws if self.wmode == "bf16" else None
             for li, p in enumerate(self.layers):
                 x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
-                self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, None, s.qkv_size, 0 if llama else 1, 1, 0)
+                self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, 1, 0)
                 self._kvwrite(li, qkv, None, 1, None, tok_pos, tok_seq)
                 self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
-                self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, None, H, 2 if llama else 3, 1, 0)
+                self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 2 if llama else 3, 1, 0)
                 x2 = norm(None, 1, None, p["ln2_w"], p.get("ln2_b"))
                 if llama:
-                    self._gemm(wk, act, x2, p, "w_gu", None, None, None, 2 * I, 4, 1, 0)
-                    self._gemm(wk, h, act, p, "w_down", None, h, None, H, 2, 1, 0)
+                    self._gemm(wk, act, x2, p, "w_gu", None, None, lws, 2 * I, 4, 1, 0)
+                    self._gemm(wk, h, act, p, "w_down", None, h, lws, H, 2, 1, 0)
                 else:
-                    self._gemm(wk, act, x2, p, "w_fc", p["b_fc"], None, None, I, 5, 1, 0)
-                    self._gemm(wk, h, act, p, "w_down", p["b_down"], h, None, H, 3, 1, 0)
+                    self._gemm(wk, act, x2, p, "w_fc", p["b_fc"], None, lws, I, 5, 1, 0)
+                    self._gemm(wk, h, act, p, "w_down", p["b_down"], h, lws, H, 3, 1, 0)
             return None
         # decode regime: weight-streaming GEMMs write fp32 split-K partials which the NEXT kernel
         # (norm / rope) sums while it reads them anyway — no reduce launches, no bf16 round trip

@@ -201,23 +201,20 @@ void rope_kvwrite8(Tensor qkv, OptTensor partial, int64_t splits, OptTensor pbia
   rope_kvwrite_impl(qkv, partial, splits, pbias, kv_cache, kv_scale, cos_t, sin_t, tok_pos, tok_seq, block_table, Hq, Hkv, D, use_rope);
 }
 
-// Kernel for bf16 GEMMs of more than 256 rows: 0 = default (2), 1 = 256 x 256 tiles, 2 = the streaming
-// kernel walking 256-row blocks, 3 = 128 x 128 tiles, 4 = the streaming kernel with 128- / 64-row blocks on
-// shapes with few column blocks (this one also applies to the fp8 x fp8 GEMM). Starts from DLIA_GEMM_LARGE (big / stream /
-// tile); the `large_gemm_kernel` op changes it for A/B runs and tests.
-static std::atomic<int>& large_gemm_choice() {
-  static std::atomic<int> v{[] {
-    const char* e = getenv("DLIA_GEMM_LARGE");
-    if (!e) return 0;
-    return e[0] == 'b' ? 1 : (e[0] == 's' ? 2 : (e[0] == 't' ? 3 : 0));
-  }()};
-  return v;
+// Kernel for bf16 GEMMs of more than 256 rows: 0 = default (256 x 256 ping-pong tiles, gemm_pingpong.hip),
+// 2 = the 256 x 128 loader-wave kernel walking 256-row blocks (gemm_rows.hip), 4 = the same with 128- / 64-row
+// blocks on shapes with few column blocks (this one also applies to the fp8 x fp8 GEMM). Starts from
+// DLIA_GEMM_LARGE=stream; the `large_gemm_kernel` op changes it for A/B runs and tests. Returns the old value.
+// floats of workspace a bf16 GEMM of this shape wants (0: none): the in-launch split-K of the large-M kernel
+int64_t gemm_ws_floats(int64_t M, int64_t N, int64_t K) {
+  return M > 256 ? dlia_gemm_pingpong_ws_floats((int)M, (int)N, (int)K) : 0;
 }
+
 int64_t large_gemm_kernel(int64_t which) {
-  DLIA_CHECK(which >= 0 && which <= 4, "large_gemm_kernel: 0 default, 1 big, 2 stream, 3 tile, 4 stream with narrow row blocks");
+  DLIA_CHECK(which == 0 || which == 2 || which == 4, "large_gemm_kernel: 0 ping-pong (default), 2 stream, 4 stream with narrow row blocks");
   const int narrow_before = dlia_gemm_rows_set_narrow(which == 4 ? 1 : 0);
-  const int before = large_gemm_choice().exchange(which == 4 ? 2 : (int)which);
-  return (before == 2 || before == 0) && narrow_before ? 4 : before;
+  const int before = dlia_gemm_large_choice(which == 4 ? 2 : (int)which);
+  return before == 2 && narrow_before ? 4 : before;
 }
 
 // out[M, N_out] = epi(x[M,K] @ W^T); wp = packed weights (uint8 view of the packed image).
@@ -301,28 +298,22 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
     }
   } else {
     DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
-    // bf16, more than 256 rows. DLIA_GEMM_LARGE picks the kernel for A/B runs: "big" (256 x 256
-    // tiles), "stream" (256 x 128, the decode kernel walking row blocks), "tile" (128 x 128).
-    int k = large_gemm_choice().load();
-    if (k == 0) k = 2;
-    if (k == 1)
-      dlia_gemm_big(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
-                    out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
-    else if (k == 2) {
-      // (a workspace given here is only ever used as the debug buffer of the kernel's diagnostic build)
-      float* dbg = nullptr;
-      if (workspace.has_value()) {
-        check_f32(*workspace, "workspace");
+    // A workspace lets the ping-pong kernel split K on shapes with fewer tiles than CUs: slabs in front, and
+    // its LAST 4096 words are arrival counters (zero when first handed over, left zero by every launch). A
+    // workspace too small for a shape's split simply is not used. For the loader-wave kernel a workspace is
+    // only ever the debug buffer of its diagnostic build.
+    float* wsp = nullptr; int64_t wsn = 0;
+    if (workspace.has_value()) {
+      check_f32(*workspace, "workspace");
+      DLIA_CHECK(workspace->is_contiguous(), "gemm workspace must be contiguous");
+      if (dlia_gemm_large_choice(-1) != 0) {
         const int64_t wgs = ((N + 127) / 128 + 7) / 8 * 8 * ((M + 255) / 256);
-        DLIA_CHECK(workspace->is_contiguous() && workspace->numel() >= wgs * 12 * 16, "debug buffer too small");
-        dbg = workspace->data_ptr<float>();
+        DLIA_CHECK(workspace->numel() >= wgs * 12 * 16, "debug buffer too small");
       }
-      dlia_gemm_skinny(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, dbg, nullptr, (int)M, (int)N, (int)K,
-                       x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, 1, 2, stream);
+      wsp = workspace->data_ptr<float>(); wsn = workspace->numel();
     }
-    else
-      dlia_gemm_tile(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, (int)M, (int)N, (int)K, x.stride(0),
-                     out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
+    dlia_gemm_large(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, wsp, wsn, (int)M, (int)N, (int)K,
+                    x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
   }
 }
 
@@ -531,6 +522,7 @@ TORCH_LIBRARY(dlia, m) {
   m.def("gemm_config(int M, int N, int K, int epi, bool allow_split) -> int[]");
   m.def("gemm_splitk(int M, int N, int K) -> int");
   m.def("large_gemm_kernel(int which) -> int");
+  m.def("gemm_ws_floats(int M, int N, int K) -> int");
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
   m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
   m.def("sample(Tensor(a!) out_tokens, Tensor logits, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
@@ -556,6 +548,7 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
 TORCH_LIBRARY_IMPL(dlia, CompositeExplicitAutograd, m) {
   m.impl("gemm_splitk", &gemm_splitk);
   m.impl("large_gemm_kernel", &large_gemm_kernel);
+  m.impl("gemm_ws_floats", &gemm_ws_floats);
   m.impl("gemm_config", &gemm_config);
   m.impl("attention_ws_floats", &attention_ws_floats);
 }

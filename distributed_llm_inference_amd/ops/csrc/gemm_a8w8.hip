@@ -269,6 +269,7 @@ extern "C" void dlia_gemm_a8w8(void* out, const void* xq, const float* xscale, c
                                hipStream_t stream) {
   if (M <= 0 || N <= 0) return;
   GemmParams p;
+  p.counters = nullptr; p.group_n = 1;
   p.x = (const bf16*)xq; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = wscale; p.xscale = xscale;
   p.out = out; p.ldo = ldo;
   p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;

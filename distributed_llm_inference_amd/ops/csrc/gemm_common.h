@@ -21,6 +21,7 @@ struct GemmParams {
   int out_f32;
   int partial_only;           // write fp32 partials even when splitk == 1 (a consumer kernel sums them)
   int group_n;                // gemm_rows.hip only: column blocks per workgroup-order group (set by its launcher)
+  int* counters;              // gemm_pingpong.hip with splitk > 1: one arrival counter per output tile, zero between launches
 };
 
 __device__ __forceinline__ void store4(void* out, long ldo, int m, int n, const float (&v)[4], int out_f32) {
@@ -57,10 +58,11 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
 
 // Output stage shared by the streaming kernels: acc[i][j][r] = C[m = m0 + i*16 + l15][n = (tile0+j)*16 + quad*4 + r].
 // Writes fp32 partials (split-K or partial-only), or applies the fused epilogue.
-template <int MT, int NTW>
+// DIRECT: the accumulators are already complete (the kernel summed its K splits itself).
+template <int MT, int NTW, bool DIRECT = false>
 __device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc)[MT][NTW], int tile0, int l15,
                                                 int quad, int ks, int m0 = 0) {
-  if (p.partial_only || p.splitk > 1) {
+  if (!DIRECT && (p.partial_only || p.splitk > 1)) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int m = m0 + i * 16 + l15;
@@ -108,6 +110,10 @@ extern "C" void dlia_splitk_reduce(const dlia::GemmParams* p, hipStream_t stream
 extern "C" void dlia_gemm_rows(const dlia::GemmParams* p, hipStream_t stream);
 extern "C" void dlia_gemm_rows_f8(const dlia::GemmParams* p, hipStream_t stream);
 extern "C" int dlia_gemm_rows_set_narrow(int on);
+extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream);
+extern "C" int dlia_gemm_large_choice(int which);
+extern "C" int dlia_gemm_pingpong_splitk(int M, int N, int K);
+extern "C" long dlia_gemm_pingpong_ws_floats(int M, int N, int K);
 extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_split, int* ntw_out, int* splitk_out);
 namespace dlia {
 

@@ -1,0 +1,345 @@
+// Compute-bound GEMM for more than 256 rows (large decode micro-batches, prefill chunks):
+// out[M,N] = epi(x[M,K] @ W[N,K]^T), bf16, 256 x 256 output tile per workgroup, K walked in 64-wide
+// tiles, both operands moved global -> LDS by DMA, MFMA 16x16x32.
+//
+// Structure ("ping-pong"): 8 waves, two per SIMD. The waves of a SIMD alternate roles every
+// barrier interval: while one runs a cluster of 16 MFMAs (one quadrant of its 128 x 64 output for
+// one K-tile), its partner issues the LDS fragment reads of ITS next quadrant and two DMA pieces
+// of a future K-tile; at the next barrier they swap. The matrix pipe of a SIMD therefore sees one
+// MFMA cluster after the other with no fragment read, DMA issue or wait in between, and every
+// fragment read has a whole interval to land before its consumer starts. Waves 4-7 run one
+// interval behind waves 0-3 (they take one extra barrier at the start, waves 0-3 one at the end).
+//
+// A K-tile is four 16 KiB half-tiles: A0 / A1 = x rows [0,128) / [128,256) of the block, B0 / B1 =
+// weight columns [0,128) / [128,256). A wave owns 64 rows of EACH row half and 32 columns of EACH
+// column half, so in every phase all eight waves work on the same pair of half-tiles:
+//   q0: A0 x B0   (reads A0: 8 fragments, B0: 4)      q1: A0 x B1   (reads B1: 4)
+//   q2: A1 x B1   (reads A1: 8)                        q3: A1 x B0   (B0 still in registers)
+// 24 fragment reads per 64 MFMAs and wave (the 256 x 128-tile kernel of gemm_rows.hip: 20 per 32),
+// half the DMA bytes per FLOP: less LDS and L2 energy per MFMA, which on this power-limited chip
+// is clock, not just cycles.
+//
+// LDS: 2 K-tiles x 4 half-tiles = 128 KiB. The DMA stream is the sequence A0 B0 B1 A1 per K-tile
+// (first-use order); phase P = 4 t + q issues half-tile number P + 6, two 1 KiB pieces per wave.
+//  * write-after-read: the slot being refilled held the same half of K-tile (number - 8) / 4,
+//    last read in phase number - 8 + {0,0,1,2}[kind] <= P - 2. Reads are issued in the first
+//    interval of a phase and complete (lgkmcnt(0)) in its second, so two phases later every wave
+//    of both groups has them in registers before any wave issues the DMA.
+//  * read-after-write: at q3 every wave waits (counted vmcnt) until only the half-tile it issued in
+//    q2 may still be in flight, i.e. its pieces of the NEXT K-tile have landed; the two barriers
+//    between that wait and the next q0 reads (one for each group's wait) make that true for all
+//    waves' pieces. Past the end of K the stream re-reads the last tile into slots nobody reads
+//    again, so the count stays exact.
+// Split-K (shapes with fewer output tiles than CUs, e.g. N = 4096 at 1024 rows = 64 tiles): the S
+// workgroups of a tile run side by side on one XCD, each over 1/S of K, and the last of them to
+// finish sums the tile (see the end of the kernel): S - 1 slabs of 256 KiB written and read once.
+// Weights are the packed-B image (ops/packing.py): a (n-tile, k-step) block is 64 lanes x 16 B in
+// fragment order, lane-linear in LDS, conflict-free; x rows are 128 B with the 16-B slot
+// XOR-swizzled by (row >> 1) & 7 on the DMA source column and on the read.
+//
+// Replaces the nn.Linear calls inside HF LlamaDecoderLayer that the reference runs on CPU in fp32
+// (Worker1.py:128-137) and the lm_head (orchestration.py:141).
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+#include "common.h"
+#include "gemm_common.h"
+#include "launch.h"
+
+namespace dlia {
+
+constexpr int kPPThreads = 512;
+constexpr int kPPHalf = 16384;                   // bytes of one half-tile
+constexpr int kPPLds = 8 * kPPHalf;              // 2 K-tiles x {A0, B0, B1, A1}
+constexpr int kPPSlab = 256 * 256;               // floats of one partial tile
+constexpr int kPPCounters = 4096;                // counter words at the end of the workspace (two per output tile)
+
+// 16 B per lane, global -> LDS: lane l lands at lds_addr + 16 l. M0 carries the wave-uniform LDS
+// address and is restored, since the compiler does not expect inline asm to change it.
+__device__ __forceinline__ void pp_dma16(const void* gptr, unsigned lds_addr) {
+  unsigned saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+               "s_nop 0\n\ts_mov_b32 m0, %0"
+               : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pp_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+__global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;       // 64-row strip of each row half, 32-column strip of each column half
+
+  // Workgroup ids go round-robin over the 8 XCDs. The row blocks of one column block run on one
+  // XCD back to back, so its weight panel comes from HBM once and from that XCD's L2 afterwards.
+  const int mblocks = (p.M + 255) >> 8;
+  const int nb = (p.ntiles + 15) >> 4;           // 256-column blocks (the last may have one column half only)
+  // ... and the K splits of one tile are neighbours in that order: dispatched together, done together.
+  const int within = blockIdx.x >> 3;
+  const int ks = within % p.splitk, rest = within / p.splitk;
+  const int cb = (rest / mblocks) * 8 + (blockIdx.x & 7);
+  if (cb >= nb) return;                          // grid padded to 8 column blocks; whole workgroup, before any barrier
+  const int mblk = rest % mblocks, mrow0 = mblk * 256;
+  const int tiles_total = p.K >> 6, KT = tiles_total * 2;
+  const int per = (tiles_total + p.splitk - 1) / p.splitk;
+  const int c0 = ks * per;
+  const int n = min(tiles_total, c0 + per) - c0;   // K-tiles of this split (>= 1 by the launcher)
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  // ---- DMA sources: per half-tile this wave moves pieces 2 wave and 2 wave + 1 -----------------
+  // x piece: 8 rows x 128 B (rows past M re-read the last row; never stored). weight piece: one
+  // (n-tile, k-step) block; a column half past the packed width re-reads n-tile `wave` (never stored).
+  const long ldxb = p.ldx * 2;
+  const char* asrc[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 16 * wave + 8 * e + (lane >> 3);
+      const int slot = (lane & 7) ^ ((r >> 1) & 7);
+      asrc[h][e] = reinterpret_cast<const char*>(p.x) + (long)min(mrow0 + h * 128 + r, p.M - 1) * ldxb + slot * 16 + (long)c0 * 128;
+    }
+  const char* bsrc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int nt = cb * 16 + h * 8 + wave;
+    bsrc[h] = reinterpret_cast<const char*>(p.wp) + ((long)(nt < p.ntiles ? nt : wave) * KT + (long)c0 * 2) * 1024 + lane * 16;
+  }
+  // kind: 0 A0, 1 B0, 2 B1, 3 A1 (the order of the stream); c = K-tile of this split; par = its LDS buffer
+  auto issue = [&](auto kind_c, int c, int par) {
+    constexpr int kind = decltype(kind_c)::value;
+    const int cc = min(c, n - 1);
+    const unsigned dst = lds0 + (par * 4 + kind) * kPPHalf + wave * 2048;
+    if constexpr (kind == 0 || kind == 3) {
+      constexpr int h = kind == 3 ? 1 : 0;
+      pp_dma16(asrc[h][0] + (long)cc * 128, dst);
+      pp_dma16(asrc[h][1] + (long)cc * 128, dst + 1024);
+    } else {
+      constexpr int h = kind == 2 ? 1 : 0;
+      pp_dma16(bsrc[h] + (long)cc * 2048, dst);
+      pp_dma16(bsrc[h] + (long)cc * 2048 + 1024, dst + 1024);
+    }
+  };
+
+  f32x4 acc[2][2][4][2];                         // [row half][column half][m-tile][n-tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 af[4][2], b0[2][2], b1[2][2];            // fragments: x of the current row half, weights of both column halves
+
+  const int xoff = (wr * 64 + l15) * 128;
+  const int sw = (l15 >> 1) & 7;
+  const int boff = wc * 4096 + lane * 16;
+  auto read_a = [&](int par, auto half_c) {
+    constexpr int h = decltype(half_c)::value;
+    const char* base = smem + (par * 4 + (h ? 3 : 0)) * kPPHalf + xoff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        af[i][kk] = *reinterpret_cast<const u32x4*>(base + i * 2048 + (((kk * 4 + quad) ^ sw) << 4));
+  };
+  auto read_b = [&](int par, auto half_c, u32x4 (&bf)[2][2]) {
+    constexpr int h = decltype(half_c)::value;
+    const char* base = smem + (par * 4 + (h ? 2 : 1)) * kPPHalf + boff;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) bf[j][kk] = *reinterpret_cast<const u32x4*>(base + (j * 2 + kk) * 1024);
+  };
+  auto cluster = [&](f32x4 (&c)[4][2], const u32x4 (&bf)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[i][j] = mfma16(bf[j][kk], af[i][kk], c[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // One phase = [fragment reads + DMA issue] barrier [MFMA cluster] barrier. t = K-tile, par = t & 1.
+  auto phase = [&](auto q_c, int t, int par) {
+    constexpr int q = decltype(q_c)::value;
+    if constexpr (q == 3) pp_wait_vm<2>();       // my pieces of K-tile t + 1 have landed (A0 of t + 2 may be in flight)
+    if constexpr (q == 0) { read_b(par, ic<0>{}, b0); __builtin_amdgcn_sched_barrier(0); read_a(par, ic<0>{}); }
+    if constexpr (q == 1) read_b(par, ic<1>{}, b1);
+    if constexpr (q == 2) read_a(par, ic<1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    // half-tile number 4 t + q + 6
+    if constexpr (q == 0) issue(ic<2>{}, t + 1, par ^ 1);
+    if constexpr (q == 1) issue(ic<3>{}, t + 1, par ^ 1);
+    if constexpr (q == 2) issue(ic<0>{}, t + 2, par);
+    if constexpr (q == 3) issue(ic<1>{}, t + 2, par);
+    pp_barrier();
+    if constexpr (q == 0) cluster(acc[0][0], b0);
+    if constexpr (q == 1) cluster(acc[0][1], b1);
+    if constexpr (q == 2) cluster(acc[1][1], b1);
+    if constexpr (q == 3) cluster(acc[1][0], b0);
+    pp_barrier();
+  };
+
+  // prologue: K-tile 0 whole, A0 and B0 of K-tile 1
+  issue(ic<0>{}, 0, 0); issue(ic<1>{}, 0, 0); issue(ic<2>{}, 0, 0); issue(ic<3>{}, 0, 0);
+  issue(ic<0>{}, 1, 1); issue(ic<1>{}, 1, 1);
+  pp_wait_vm<4>();                               // K-tile 0 has landed (my pieces)
+  pp_barrier();                                  // ... and everyone's
+  if (wr == 1) pp_barrier();                     // waves 4-7 run one interval behind
+
+  for (int t = 0; t < n; t += 2) {
+    phase(ic<0>{}, t, 0); phase(ic<1>{}, t, 0); phase(ic<2>{}, t, 0); phase(ic<3>{}, t, 0);
+    if (t + 1 < n) {
+      phase(ic<0>{}, t + 1, 1); phase(ic<1>{}, t + 1, 1); phase(ic<2>{}, t + 1, 1); phase(ic<3>{}, t + 1, 1);
+    }
+  }
+  if (wr == 0) pp_barrier();                     // the barrier waves 4-7 took at the start
+  pp_wait_vm<0>();                               // no DMA may land after the workgroup is gone
+
+  if (p.splitk > 1) {
+    // ---- sum the K splits of this tile ------------------------------------------------------
+    // Each workgroup first draws a ticket from the tile's arrival counter. All but the last to
+    // arrive store their accumulators (write-through, register order) to their slab and raise the
+    // tile's second counter; the last one, which never stores, waits until that counter shows
+    // every slab complete — a wait for workgroups that are already running and wait for nothing
+    // themselves, so it cannot deadlock whatever else is resident — adds the slabs to its
+    // registers and runs the fused epilogue.
+    const int tile = cb * mblocks + mblk;
+    int* const arrived = p.counters + 2 * tile;
+    int* const stored = arrived + 1;
+    float* const slabs = p.partial + (long)tile * (p.splitk - 1) * kPPSlab;
+    int* const lds_word = reinterpret_cast<int*>(smem);      // the staging area is dead; one LDS object only
+    __syncthreads();
+    if (tid == 0) *lds_word = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *lds_word;
+    if (ticket != p.splitk - 1) {
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(slabs + (long)ticket * kPPSlab, 0, kPPSlab * 4, 0x00020000);
+#pragma unroll
+      for (int f = 0; f < 32; ++f) {
+        const f32x4 v = acc[f >> 4][(f >> 3) & 1][(f >> 1) & 3][f & 1];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (f * kPPThreads + tid) * 16, 0, 16);   // sc1
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains, then one lane signals
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(stored, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;                                                // whole workgroup
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.splitk - 1)
+        __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < p.splitk - 1; ++s) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(slabs + (long)s * kPPSlab) + tid;
+#pragma unroll
+      for (int f0 = 0; f0 < 32; f0 += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(f0 + u) * kPPThreads];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int f = f0 + u;
+          acc[f >> 4][(f >> 3) & 1][(f >> 1) & 3][f & 1] += t[u];
+        }
+      }
+    }
+    if (tid == 0) {                                          // both counters back to zero for the next launch
+      __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(stored, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+      write_acc_tiles<4, 2, true>(p, acc[hm][hn], cb * 16 + hn * 8 + wc * 2, l15, quad, 0, mrow0 + hm * 128 + wr * 64);
+}
+
+}  // namespace dlia
+
+using namespace dlia;
+
+// Which kernel serves bf16 GEMMs of more than 256 rows: 0 = this one (default), 2 = the 256 x 128
+// loader-wave kernel of gemm_rows.hip (also: DLIA_GEMM_LARGE=stream). which < 0 only reads.
+extern "C" int dlia_gemm_large_choice(int which) {
+  static std::atomic<int> v{[] { const char* e = getenv("DLIA_GEMM_LARGE"); return (e && e[0] == 's') ? 2 : 0; }()};
+  return which < 0 ? v.load() : v.exchange(which);
+}
+
+// K splits for a shape: as many as keep the launch within `target` workgroups (default 128: half the
+// CUs — the serving path runs two micro-batches on two streams, and a thin launch shares the chip
+// with the other stream's kernels), each split at least 8 K-tiles long, at most 8 splits.
+extern "C" int dlia_gemm_pingpong_splitk(int M, int N, int K) {
+  static const int target = [] { const char* e = getenv("DLIA_GEMM_PP_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+  const int tiles = ((M + 255) / 256) * ((packed_ntiles(N) + 15) / 16), ktiles = K / 64;
+  if (tiles > kPPCounters / 2) return 1;
+  int s = target / tiles;
+  if (s > 8) s = 8;
+  while (s > 1 && ktiles / s < 8) --s;
+  return s < 1 ? 1 : s;
+}
+// Workspace the split needs: slabs [tiles][S][256 x 256]; the arrival counters are the LAST
+// kPPCounters words of whatever workspace the caller hands over (so that workspaces shared with
+// other users of their front part keep them intact).
+extern "C" long dlia_gemm_pingpong_ws_floats(int M, int N, int K) {
+  const long tiles = (long)((M + 255) / 256) * ((packed_ntiles(N) + 15) / 16);
+  const int s = dlia_gemm_pingpong_splitk(M, N, K);
+  return s > 1 ? tiles * (s - 1) * kPPSlab + kPPCounters : 0;
+}
+
+// bf16, M > 256 (any M is correct; below that the weight-streaming kernels are faster), K a
+// multiple of 64; `p` fully set up by the caller. p->splitk > 1 needs p->partial = slabs for
+// [tiles][splitk - 1] and p->counters = two zero words per tile (the kernel leaves them zero).
+extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pingpong_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kPPLds);
+    return true;
+  }();
+  (void)once;
+  const int nb = (p->ntiles + 15) / 16, nb8 = (nb + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
+  hipLaunchKernelGGL(gemm_pingpong_kernel, dim3(nb8 * mblocks * p->splitk), dim3(kPPThreads), kPPLds, stream, *p);
+}
+
+// out[M,N] = epi(x[M,K] @ Wp^T) for bf16 weights and more than 256 rows (epilogues 0..5 as
+// dlia_gemm_skinny). `workspace` (may be null) of `ws_floats` floats: lets thin shapes split K; its
+// last 4096 words are the arrival counters (zero when first handed over, zero after every launch).
+extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const void* bias, const void* residual,
+                                float* workspace, long ws_floats, int M, int N, int K, long ldx, long ldo, long ldr,
+                                int epi, int out_f32, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return;
+  GemmParams p;
+  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = nullptr; p.xscale = nullptr; p.out = out; p.ldo = ldo;
+  p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;
+  p.residual = (epi == 2 || epi == 3) ? (const bf16*)residual : nullptr;
+  p.ldr = ldr; p.partial = workspace; p.M = M; p.N = N; p.K = K;
+  p.ntiles = packed_ntiles(N);
+  p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
+  p.out_f32 = out_f32; p.partial_only = 0; p.splitk = 1; p.group_n = 1; p.counters = nullptr;
+  if (dlia_gemm_large_choice(-1) != 0) { dlia_gemm_rows(&p, stream); return; }
+  const int s = dlia_gemm_pingpong_splitk(M, N, K);
+  if (workspace && s > 1 && ws_floats >= dlia_gemm_pingpong_ws_floats(M, N, K)) {
+    p.splitk = s;
+    p.counters = reinterpret_cast<int*>(workspace + ws_floats - kPPCounters);
+  }
+  dlia_gemm_pingpong(&p, stream);
+}

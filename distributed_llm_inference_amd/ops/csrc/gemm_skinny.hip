@@ -585,6 +585,7 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
                                  int out_f32, int splitk, int ntw, hipStream_t stream) {
   if (M <= 0 || N <= 0) return;
   GemmParams p;
+  p.counters = nullptr; p.group_n = 1;
   p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = wscale; p.xscale = nullptr; p.out = out; p.ldo = ldo;
   p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;
   p.residual = (epi == 2 || epi == 3) ? (const bf16*)residual : nullptr;

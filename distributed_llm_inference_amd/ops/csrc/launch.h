@@ -53,16 +53,20 @@ void dlia_gemm_a8w8(void* out, const void* xq, const float* xscale, const void* 
 // per-row dynamic e4m3 quantisation of bf16 activations: q[M,K] bytes (row stride ldq), scale[M]
 void dlia_quant_rows(void* q, float* scale, const void* x, int M, int K, long ldx, long ldq, hipStream_t stream);
 
-// ---- gemm_tile.hip --------------------------------------------------------------------
-// Same contract for large M (prefill): 128x128x64 LDS-staged MFMA tiles.
-void dlia_gemm_tile(void* out, const void* x, const void* wp, const void* bias,
-                    const void* residual, int M, int N, int K, long ldx, long ldo, long ldr,
-                    int epi, int out_f32, hipStream_t stream);
-void dlia_gemm_big(void* out, const void* x, const void* wp, const void* bias,
-                    const void* residual, int M, int N, int K, long ldx, long ldo, long ldr,
-                    int epi, int out_f32, hipStream_t stream);
+// ---- gemm_rows.hip / gemm_pingpong.hip (more than 128 / 256 rows; reached through dlia_gemm_skinny) ----
 // 1: the streaming GEMM picks 128- / 64-row blocks on shapes with few column blocks (off by default); returns the old value
 int dlia_gemm_rows_set_narrow(int on);
+// bf16 GEMM of more than 256 rows, same epilogues as dlia_gemm_skinny (0..5). workspace / ws_floats (optional):
+// room for the in-launch split-K of thin shapes; its LAST 4096 words are arrival counters, zero between launches.
+void dlia_gemm_large(void* out, const void* x, const void* wp, const void* bias, const void* residual,
+                     float* workspace, long ws_floats, int M, int N, int K, long ldx, long ldo, long ldr,
+                     int epi, int out_f32, hipStream_t stream);
+// kernel for bf16 GEMMs of more than 256 rows: 0 = 256 x 256 ping-pong tiles (default), 2 = the loader-wave
+// kernel of gemm_rows.hip; which < 0 only reads; returns the previous choice
+int dlia_gemm_large_choice(int which);
+// the large-M kernel's in-launch split-K: factor for a shape, and the workspace floats it needs (slabs + counters)
+int dlia_gemm_pingpong_splitk(int M, int N, int K);
+long dlia_gemm_pingpong_ws_floats(int M, int N, int K);
 
 // ---- attention.hip --------------------------------------------------------------------
 // Causal GQA attention of ragged query chunks against the paged KV cache (prefill chunks and

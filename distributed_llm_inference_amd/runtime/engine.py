@@ -43,7 +43,7 @@ from .head import LocalHead
 from .kv_cache import BlockAllocator, blocks_for
 from ..ops.packing import KV_BLOCK
 from .sampler import SamplingParams
-from .tokenizer import build_prompt
+from .tokenizer import build_prompt, encode_prompt
 
 
 class EngineError(RuntimeError):
@@ -74,6 +74,21 @@ class Request:
     error: Optional[str] = None
     done: threading.Event = field(default_factory=threading.Event)
     seed: int = 0
+    callbacks: List = field(default_factory=list)     # called (from the scheduler thread) when the request is done
+
+    def _set_done(self):
+        self.done.set()
+        for cb in self.callbacks:
+            try:
+                cb(self)
+            except Exception:
+                pass
+
+    def add_done_callback(self, cb):
+        """`cb(request)` runs once the request has finished or failed (immediately if it already has)."""
+        self.callbacks.append(cb)
+        if self.done.is_set():
+            cb(self)
 
     @property
     def finished(self) -> bool:
@@ -204,6 +219,41 @@ class Engine:
         self._wake.set()
         return req
 
+    def submit_text(self, prompt: str, max_new_tokens: Optional[int] = None, temperature: Optional[float] = None,
+                    top_k: Optional[int] = None, top_p: Optional[float] = None, seed: Optional[int] = None) -> Request:
+        """Chat-format and tokenise `prompt`, clamp the token count, enqueue. The caller waits on the
+        returned request (`wait`, or `add_done_callback` from an event loop) and renders it with
+        `text_result`."""
+        text = build_prompt(self.tok, prompt, self.cfg.system_prompt, self.cfg.chat_template)
+        ids = encode_prompt(self.tok, text)
+        n = self.cfg.default_max_tokens if max_new_tokens is None else int(max_new_tokens)
+        n = max(1, min(n, self.cfg.max_tokens_cap))
+        sp = SamplingParams(temperature=self.cfg.temperature if temperature is None else float(temperature),
+                            top_k=self.cfg.top_k if top_k is None else int(top_k),
+                            top_p=self.cfg.top_p if top_p is None else float(top_p),
+                            max_new_tokens=n, seed=seed)
+        return self.submit(ids, sp)
+
+    def text_result(self, req: Request, prompt: str, start: float) -> Dict:
+        """The reference's result dictionary (orchestration.py:211-218) for a finished request, or
+        its error envelope (:220-228) for a failed one."""
+        if req.state == "failed":
+            return {"error": f"Error: {req.error or 'generation failed'}", "status": "failed"}
+        generated_text = self.tok.decode(req.output, skip_special_tokens=True)
+        elapsed = time.time() - start
+        tps = len(req.output) / elapsed if elapsed > 0 else 0
+        out = {"prompt": prompt, "response": generated_text, "status": "success",
+               "time_taken": f"{elapsed:.2f}s", "tokens_generated": len(req.output),
+               "tokens_per_sec": f"{tps:.2f}"}
+        # numeric extras (the reference's three metrics above are strings)
+        out["ttft_ms"] = round((req.t_first - req.t_arrival) * 1e3, 3) if req.t_first else None
+        if len(req.token_times) > 1:
+            gaps = sorted(b - a for a, b in zip(req.token_times, req.token_times[1:]))
+            out["tpot_ms_p50"] = round(gaps[len(gaps) // 2] * 1e3, 3)
+        if self.cfg.debug_top5:
+            out["token_ids"] = list(req.output)
+        return out
+
     def generate_text(self, prompt: str, max_new_tokens: Optional[int] = None, temperature: Optional[float] = None,
                       top_k: Optional[int] = None, top_p: Optional[float] = None, seed: Optional[int] = None,
                       timeout: Optional[float] = None) -> Dict:
@@ -211,31 +261,9 @@ class Engine:
         (orchestration.py:211-228)."""
         start = time.time()
         try:
-            text = build_prompt(self.tok, prompt, self.cfg.system_prompt, self.cfg.chat_template)
-            ids = self.tok.encode(text)
-            n = self.cfg.default_max_tokens if max_new_tokens is None else int(max_new_tokens)
-            n = max(1, min(n, self.cfg.max_tokens_cap))
-            sp = SamplingParams(temperature=self.cfg.temperature if temperature is None else float(temperature),
-                                top_k=self.cfg.top_k if top_k is None else int(top_k),
-                                top_p=self.cfg.top_p if top_p is None else float(top_p),
-                                max_new_tokens=n, seed=seed)
-            req = self.submit(ids, sp).wait(timeout or self.cfg.request_timeout_s)
-            if req.state == "failed":
-                raise EngineError(req.error or "generation failed")
-            generated_text = self.tok.decode(req.output, skip_special_tokens=True)
-            elapsed = time.time() - start
-            tps = len(req.output) / elapsed if elapsed > 0 else 0
-            out = {"prompt": prompt, "response": generated_text, "status": "success",
-                   "time_taken": f"{elapsed:.2f}s", "tokens_generated": len(req.output),
-                   "tokens_per_sec": f"{tps:.2f}"}
-            # numeric extras (the reference's three metrics above are strings)
-            out["ttft_ms"] = round((req.t_first - req.t_arrival) * 1e3, 3) if req.t_first else None
-            if len(req.token_times) > 1:
-                gaps = sorted(b - a for a, b in zip(req.token_times, req.token_times[1:]))
-                out["tpot_ms_p50"] = round(gaps[len(gaps) // 2] * 1e3, 3)
-            if self.cfg.debug_top5:
-                out["token_ids"] = list(req.output)
-            return out
+            req = self.submit_text(prompt, max_new_tokens, temperature, top_k, top_p, seed)
+            req.wait(timeout or self.cfg.request_timeout_s)
+            return self.text_result(req, prompt, start)
         except Exception as e:      # same envelope as the reference: HTTP 200, status "failed"
             return {"error": f"Error: {e}", "status": "failed"}
 
@@ -303,7 +331,7 @@ class Engine:
         req.error, req.state = msg, "failed"
         req.t_done = time.perf_counter()
         self.stats["failed"] += 1
-        req.done.set()
+        req._set_done()
 
     # ---- per-micro-batch state machine -----------------------------------------------------
     def _tick(self, mb: _MicroBatch) -> bool:
@@ -602,7 +630,7 @@ class Engine:
         self.stats["completed"] += 1
         if self.tracer is not None:
             self.tracer.instant("scheduler", "finish", {"rid": r.rid, "tokens": len(r.output)})
-        r.done.set()
+        r._set_done()
 
     # ---- introspection -----------------------------------------------------------------------
     def snapshot(self) -> Dict:

@@ -37,6 +37,7 @@ class ByteTokenizer:
         if bos_token_id is not None and 0 <= bos_token_id < vocab_size:
             self.bos_token_id = bos_token_id
         self.chat_template = None
+        self.bos_token = "<s>"
 
     def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
         ids: List[int] = [self.bos_token_id] if add_special_tokens else []
@@ -77,6 +78,7 @@ class HFTokenizer:
         self.pad_token_id = self.tk.pad_token_id
         self.vocab_size = len(self.tk)
         self.chat_template = getattr(self.tk, "chat_template", None)
+        self.bos_token = self.tk.bos_token
 
     def encode(self, text: str, add_special_tokens: bool = True) -> List[int]:
         return list(self.tk.encode(text, add_special_tokens=add_special_tokens))
@@ -114,3 +116,14 @@ def build_prompt(tokenizer, user_message: str, system_prompt: str, mode: str = "
             if mode == "hf":
                 raise
     return format_chat_prompt(user_message, system_prompt)
+
+
+def encode_prompt(tokenizer, text: str) -> List[int]:
+    """Token ids of a formatted prompt with exactly one BOS: a chat template that already begins
+    with the BOS string (Llama-3-Instruct's `<|begin_of_text|>`) is encoded without the tokenizer
+    adding another one. The reference's Zephyr template carries none and gets the usual one
+    (orchestration.py:98 encodes with the tokenizer's defaults)."""
+    bos = getattr(tokenizer, "bos_token", None)
+    if bos and text.startswith(bos):
+        return tokenizer.encode(text, add_special_tokens=False)
+    return tokenizer.encode(text)

@@ -27,7 +27,7 @@ import torch
 
 from ..config import EngineConfig
 from ..runtime.sampler import sample_token, top_candidates
-from ..runtime.tokenizer import build_prompt
+from ..runtime.tokenizer import build_prompt, encode_prompt
 
 VERSION = "dlia-mi355x-0.1"
 _HEADERS = {"ngrok-skip-browser-warning": "true", "Content-Type": "application/json"}   # orchestration.py:91-94
@@ -71,6 +71,28 @@ class EngineBackend:
         self._recover()
         return self.engine.generate_text(prompt, max_new_tokens=max_new_tokens, temperature=temperature,
                                          top_k=self.cfg.top_k, top_p=self.cfg.top_p)
+
+    async def agenerate(self, prompt, max_new_tokens, temperature):
+        """`generate` for an event loop: the coroutine is resumed by the scheduler thread's
+        completion callback, so thousands of requests can wait without a thread each."""
+        import asyncio
+        loop = asyncio.get_running_loop()
+        if self.cfg.auto_restart and self.engine.fatal:
+            await loop.run_in_executor(None, self._recover)       # rebuilding stage processes blocks
+        start = time.time()
+        engine = self.engine
+        try:
+            req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k, self.cfg.top_p)
+            fut = loop.create_future()
+
+            def wake(_req):
+                loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(None))
+
+            req.add_done_callback(wake)
+            await asyncio.wait_for(fut, timeout=self.cfg.request_timeout_s)
+            return engine.text_result(req, prompt, start)
+        except Exception as e:                                      # HTTP 200 envelope, as the reference
+            return {"error": f"Error: {e or type(e).__name__}", "status": "failed"}
 
     def workers(self) -> Dict[str, str]:
         """Stage s is reported as worker_{s+1}. online = ready with a fresh heartbeat; error = the
@@ -151,7 +173,7 @@ class HttpRelayBackend:
         seq_id = f"r{next(self._ids)}"
         try:
             text = build_prompt(self.tok, prompt, self.cfg.system_prompt, self.cfg.chat_template)
-            ids = self.tok.encode(text)
+            ids = encode_prompt(self.tok, text)
             self.stats["tokens_in"] += len(ids)
             n = max(1, min(int(max_new_tokens), self.cfg.max_tokens_cap))
             generated: List[int] = []
@@ -237,22 +259,7 @@ def create_app(backend):
 
     @app.route("/")
     def home():
-        b = app.config["backend"]
-        rows = "".join(f"<p>{d}</p>" for d in (b.worker_descriptions() if b else ["not initialized"]))
-        model = b.model_name if b else "-"
-        return f"""<!DOCTYPE html><html><head><title>Distributed LLM API</title>
-<style>body{{font-family:Arial,sans-serif;max-width:900px;margin:50px auto;padding:30px;
-background:linear-gradient(135deg,#667eea 0%,#764ba2 100%);color:white}}
-.container{{background:rgba(255,255,255,0.1);padding:40px;border-radius:20px}}
-.status{{display:inline-block;background:#4CAF50;padding:8px 20px;border-radius:25px;font-weight:bold}}
-.section{{background:rgba(0,0,0,0.2);padding:20px;border-radius:10px;margin:20px 0}}</style></head>
-<body><div class="container"><h1>Distributed LLM API</h1>
-<h2>Status: <span class="status">{'ONLINE' if b else 'STARTING'}</span></h2>
-<div class="section"><h3>Model</h3><p>{model}</p><p>Engine {VERSION}: layer-split pipeline on MI355X,
-paged KV cache, temperature / top-k / top-p sampling, chat formatting.</p></div>
-<div class="section"><h3>Workers</h3>{rows}</div>
-<div class="section"><h3>Routes</h3><p>GET /health &middot; GET /workers &middot; POST /generate &middot; GET /metrics</p></div>
-</div></body></html>"""
+        return _status_page(app.config["backend"])
 
     @app.route("/health", methods=["GET"])
     def health():
@@ -295,6 +302,88 @@ paged KV cache, temperature / top-k / top-p sampling, chat formatting.</p></div>
     return app
 
 
+def _status_page(b) -> str:
+    rows = "".join(f"<p>{d}</p>" for d in (b.worker_descriptions() if b else ["not initialized"]))
+    model = b.model_name if b else "-"
+    return f"""<!DOCTYPE html><html><head><title>Distributed LLM API</title>
+<style>body{{font-family:Arial,sans-serif;max-width:900px;margin:50px auto;padding:30px;
+background:linear-gradient(135deg,#667eea 0%,#764ba2 100%);color:white}}
+.container{{background:rgba(255,255,255,0.1);padding:40px;border-radius:20px}}
+.status{{display:inline-block;background:#4CAF50;padding:8px 20px;border-radius:25px;font-weight:bold}}
+.section{{background:rgba(0,0,0,0.2);padding:20px;border-radius:10px;margin:20px 0}}</style></head>
+<body><div class="container"><h1>Distributed LLM API</h1>
+<h2>Status: <span class="status">{'ONLINE' if b else 'STARTING'}</span></h2>
+<div class="section"><h3>Model</h3><p>{model}</p><p>Engine {VERSION}: layer-split pipeline on MI355X,
+paged KV cache, temperature / top-k / top-p sampling, chat formatting.</p></div>
+<div class="section"><h3>Workers</h3>{rows}</div>
+<div class="section"><h3>Routes</h3><p>GET /health &middot; GET /workers &middot; POST /generate &middot; GET /metrics</p></div>
+</div></body></html>"""
+
+
+def create_asgi_app(backend):
+    """The same routes as `create_app` on Starlette, for a production ASGI server (uvicorn): requests
+    wait on the engine as coroutines, not in one thread each as under the reference's Werkzeug
+    development server (orchestration.py:372)."""
+    import json
+
+    from starlette.applications import Starlette
+    from starlette.responses import HTMLResponse, JSONResponse, PlainTextResponse, Response
+    from starlette.routing import Route
+
+    state = {"backend": backend}
+    cors = {"Access-Control-Allow-Origin": "*",                              # orchestration.py:232
+            "Access-Control-Allow-Headers": "Content-Type, ngrok-skip-browser-warning",
+            "Access-Control-Allow-Methods": "GET, POST, OPTIONS"}
+
+    def js(obj, status=200):
+        return JSONResponse(obj, status_code=status, headers=cors)
+
+    async def home(request):
+        return HTMLResponse(_status_page(state["backend"]), headers=cors)
+
+    async def health(request):
+        b = state["backend"]
+        return js({"status": "healthy", "role": "orchestrator", "model": b.model_name if b else None, "version": VERSION})
+
+    async def workers(request):
+        b = state["backend"]
+        return js({"worker_1": "not_configured"} if b is None else b.workers())
+
+    async def generate(request):
+        if request.method == "OPTIONS":
+            return Response(status_code=204, headers=cors)
+        b = state["backend"]
+        if b is None:
+            return js({"error": "Orchestrator not initialized"}, 500)           # orchestration.py:335-336
+        try:
+            data = json.loads(await request.body() or b"{}")
+            if not isinstance(data, dict):
+                data = {}
+        except ValueError:
+            data = {}
+        prompt = data.get("prompt", "")
+        if not prompt:
+            return js({"error": "No prompt provided"}, 400)                      # orchestration.py:343-344
+        try:
+            max_tokens = min(int(data.get("max_tokens", b.cfg.default_max_tokens)), b.cfg.max_tokens_cap)   # orchestration.py:347
+            temperature = float(data.get("temperature", b.cfg.temperature))
+        except (TypeError, ValueError):
+            return js({"error": "max_tokens and temperature must be numbers"}, 400)
+        if hasattr(b, "agenerate"):
+            return js(await b.agenerate(prompt, max_tokens, temperature))        # HTTP 200 even when status == failed
+        from starlette.concurrency import run_in_threadpool
+        return js(await run_in_threadpool(b.generate, prompt, max_tokens, temperature))
+
+    async def metrics(request):
+        b = state["backend"]
+        return PlainTextResponse(b.metrics() if b else "", media_type="text/plain; version=0.0.4", headers=cors)
+
+    app = Starlette(routes=[Route("/", home), Route("/health", health), Route("/workers", workers),
+                            Route("/generate", generate, methods=["POST", "OPTIONS"]), Route("/metrics", metrics)])
+    app.state.dlia = state
+    return app
+
+
 def serve(cfg: EngineConfig):
     """Blocking: bring the pipeline (or the HTTP relay) up and serve the API on cfg.host:cfg.port."""
     from ..utils.tracing import get_logger
@@ -303,12 +392,21 @@ def serve(cfg: EngineConfig):
         backend = HttpRelayBackend(cfg)
         log.info("orchestrator (HTTP relay) for %s; workers: %s", backend.model_name, cfg.worker_urls)
     else:
+        import dataclasses
         from ..parallel.launcher import make_pipeline
+        if cfg.resolved_device() == "cuda" and not cfg.isolate:
+            # serving on GPUs: every stage in its own process, none in this one — a stage hung inside a
+            # device call can then always be killed and replaced while this process keeps answering
+            cfg = dataclasses.replace(cfg, isolate=True)
         backend = EngineBackend(make_pipeline(cfg))
         log.info("orchestrator for %s: %d stage(s), backend %s, transport %s", backend.model_name, cfg.pp_size,
                  cfg.resolved_backend(), cfg.resolved_transport())
-    app = create_app(backend)
     try:
-        app.run(host=cfg.host, port=cfg.port, debug=False, threaded=True)
+        if cfg.server == "flask":
+            create_app(backend).run(host=cfg.host, port=cfg.port, debug=False, threaded=True)
+        else:
+            import uvicorn
+            uvicorn.run(create_asgi_app(backend), host=cfg.host, port=cfg.port, log_level="warning",
+                        timeout_keep_alive=30, backlog=4096)
     finally:
         backend.close()

@@ -64,6 +64,44 @@ def test_orchestrator_routes(backend):
     assert "dlia_tokens_generated_total" in m and 'dlia_stage_up{stage="1"' in m
 
 
+def test_asgi_app_serves_the_same_contract(backend):
+    """The production front door (Starlette under uvicorn) answers exactly like the Flask app: same
+    routes, status codes, JSON schemas, CORS header and HTTP-200 error envelope; and many requests
+    wait concurrently as coroutines."""
+    from concurrent.futures import ThreadPoolExecutor
+    from starlette.testclient import TestClient
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    with TestClient(create_asgi_app(backend)) as c:
+        r = c.get("/health")
+        assert r.status_code == 200 and set(r.json()) == {"status", "role", "model", "version"}
+        assert c.get("/workers").json() == {"worker_1": "online", "worker_2": "online"}
+        r = c.get("/")
+        assert r.status_code == 200 and "Distributed LLM API" in r.text and "stage 1" in r.text
+        r = c.post("/generate", json={"prompt": "Hello", "max_tokens": 6})
+        d = r.json()
+        assert r.status_code == 200 and d["status"] == "success" and d["prompt"] == "Hello"
+        assert {"prompt", "response", "status", "time_taken", "tokens_generated", "tokens_per_sec"} <= set(d)
+        assert isinstance(d["time_taken"], str) and d["time_taken"].endswith("s") and isinstance(d["tokens_per_sec"], str)
+        assert r.headers["Access-Control-Allow-Origin"] == "*"
+        assert c.post("/generate", json={"max_tokens": 3}).status_code == 400
+        assert c.post("/generate", json={"prompt": ""}).json() == {"error": "No prompt provided"}
+        assert c.post("/generate", json={"prompt": "x", "max_tokens": "many"}).status_code == 400
+        assert c.options("/generate").status_code == 204
+        r = c.post("/generate", json={"prompt": "x" * 4000})
+        assert r.status_code == 200 and r.json()["status"] == "failed" and r.json()["error"].startswith("Error: ")
+        a = c.post("/generate", json={"prompt": "Hi", "max_tokens": 5, "temperature": 0}).json()
+        flask_answer = create_app(backend).test_client().post("/generate", json={"prompt": "Hi", "max_tokens": 5, "temperature": 0}).get_json()
+        assert a["status"] == "success" and a["response"] == flask_answer["response"]
+        assert "dlia_tokens_generated_total" in c.get("/metrics").text
+        with ThreadPoolExecutor(16) as ex:
+            outs = list(ex.map(lambda i: c.post("/generate", json={"prompt": f"q{i}", "max_tokens": 4, "temperature": 0}).json(), range(32)))
+        assert all(o["status"] == "success" for o in outs)
+    with TestClient(create_asgi_app(None)) as c:
+        r = c.post("/generate", json={"prompt": "x"})
+        assert r.status_code == 500 and r.json() == {"error": "Orchestrator not initialized"}
+        assert c.get("/workers").json() == {"worker_1": "not_configured"}
+
+
 def test_orchestrator_not_initialised():
     c = create_app(None).test_client()
     r = c.post("/generate", json={"prompt": "x"})

@@ -344,13 +344,13 @@ def test_gemm_a8w8_large_m_llama_shape(K):
     _gemm_a8w8_case(K, 512, 1152, 1024, 0, 1, out_f32=True)      # 72 n-tiles: 9 column blocks, grid padded to 16
 
 
-LARGE_KERNELS = {"stream": 2, "big": 1, "tile": 3}     # see the `large_gemm_kernel` op
+LARGE_KERNELS = {"pingpong": 0, "stream": 2}     # see the `large_gemm_kernel` op
 
 
 @pytest.fixture(params=sorted(LARGE_KERNELS))
 def large_kernel(K, request):
-    """Each kernel for more than 256 rows in turn: the streaming kernel walking 256-row blocks (the
-    default), the 256 x 256-tile kernel and the 128 x 128-tile kernel."""
+    """Each kernel for more than 256 rows in turn: the 256 x 256 ping-pong kernel (the default) and the
+    256 x 128 loader-wave kernel walking 256-row blocks."""
     prev = K.large_gemm_kernel(LARGE_KERNELS[request.param])
     yield request.param
     K.large_gemm_kernel(prev)
@@ -365,6 +365,81 @@ def test_gemm_large_m(K, large_kernel, M, epi):
 
 def test_gemm_large_m_llama_shape(K, large_kernel):
     _gemm_case(K, 1024, 6144, 4096, 2, 1)
+
+
+@pytest.mark.parametrize("shape", [(1024, 28672, 4096, 4), (1024, 4096, 14336, 2), (2048, 6144, 4096, 0),
+                                   (1000, 1152, 12288, 3), (4100, 1024, 384, 0), (520, 384, 128, 5)])
+def test_gemm_pingpong_shapes(K, shape):
+    """The default large-M kernel on the Llama-3-8B layer shapes at a 1024-row micro-batch (SwiGLU and
+    residual epilogues), a long and a minimal K (two K-tiles), a column count that leaves the last
+    256-column block half empty, and row counts that end inside a block."""
+    M, N, Kd, epi = shape
+    prev = K.large_gemm_kernel(0)
+    try:
+        _gemm_case(K, M, N, Kd, epi, 1)
+    finally:
+        K.large_gemm_kernel(prev)
+
+
+@pytest.mark.parametrize("shape", [(1024, 4096, 4096, 2), (1024, 6144, 4096, 0), (1024, 4096, 14336, 2), (512, 4096, 4096, 3),
+                                   (700, 1152, 2048, 4), (300, 384, 1024, 5)])
+def test_gemm_pingpong_split_k_inside_the_launch(K, shape):
+    """Shapes with fewer 256 x 256 tiles than CUs split K over neighbouring workgroups; the last one
+    to finish a tile adds the others' accumulators and runs the fused epilogue. Run repeatedly on one
+    workspace: the arrival counters (its last 4096 words) must be back at zero after every launch, and
+    an odd number of K-tiles per split (64 tiles / 3) must work."""
+    M, N, Kd, epi = shape
+    prev = K.large_gemm_kernel(0)
+    try:
+        need = int(K.gemm_ws_floats(M, N, Kd))
+        assert need > 0, "shape does not split: not a test of the split path"
+        torch.manual_seed(1)
+        x = bf(torch.randn(M, Kd, device=DEV))
+        if epi == 4:
+            wg, wu = (bf(torch.randn(N // 2, Kd, device=DEV) / math.sqrt(Kd)) for _ in range(2))
+            wp, w_ref, n_out = packing.pack_weight(packing.interleave_gate_up(wg, wu)), torch.cat([wg, wu], 0), N // 2
+        else:
+            w_ref = bf(torch.randn(N, Kd, device=DEV) / math.sqrt(Kd))
+            wp, n_out = packing.pack_weight(w_ref), N
+        bias, res = bf(torch.randn(n_out, device=DEV)), bf(torch.randn(M, n_out, device=DEV))
+        want = ref.gemm(x, w_ref, bias, res, epi)
+        ws = torch.zeros(need + 4096, device=DEV, dtype=torch.float32)
+        for it in range(4):
+            out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.bfloat16)
+            K.gemm(out, x, wp, bias, res, ws, N, epi, 1, 0)
+            assert_close(out, want, 3e-2, 2e-2, f"split-K gemm {shape} launch {it}")
+            assert int(ws[-4096:].view(torch.int32).abs().sum()) == 0, "arrival counters not reset"
+        # a workspace used by someone else in front (decode partials) is fine: only the tail is sacred
+        ws[:need].uniform_(-1e6, 1e6)
+        out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.bfloat16)
+        K.gemm(out, x, wp, bias, res, ws, N, epi, 1, 0)
+        assert_close(out, want, 3e-2, 2e-2, f"split-K gemm {shape} dirty workspace")
+    finally:
+        K.large_gemm_kernel(prev)
+
+
+def test_gemm_pingpong_exact_on_integer_data_with_asymmetric_operands(K):
+    """Small integers are exact in bf16 and fp32: every output element must equal the integer product
+    exactly, with an x that is not symmetric and weights that differ per column (a swapped row/column
+    map, a mis-placed K-tile or a fragment read racing its DMA cannot pass)."""
+    from distributed_llm_inference_amd.ops import packing
+    M, N, Kd = 768, 512, 896
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randint(-3, 4, (M, Kd), device=DEV, generator=g).float()
+    w = torch.randint(-2, 3, (N, Kd), device=DEV, generator=g).float()
+    w[:, 0] += torch.arange(N, device=DEV).float() % 5
+    want = x @ w.t()
+    out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    prev = K.large_gemm_kernel(0)
+    try:
+        ws = torch.zeros(int(K.gemm_ws_floats(M, N, Kd)) + 4096, device=DEV, dtype=torch.float32)
+        for it in range(20):                 # a race would come and go
+            out.zero_()
+            K.gemm(out, x.to(torch.bfloat16), packing.pack_weight(w.to(torch.bfloat16)), None, None,
+                   ws if it % 2 else None, N, 0, 1, 0)      # alternately split over K inside the launch and not
+            assert torch.equal(out, want)
+    finally:
+        K.large_gemm_kernel(prev)
 
 
 def test_gemm_large_m_row_block_tiers(K):

@@ -321,3 +321,27 @@ def test_shm_ring_and_status_board():
     b.set_state(1, 3, "boom")
     assert b.read(1)["state"] == "error" and b.read(1)["error"] == "boom"
     b.close()
+
+
+def test_templates_that_carry_their_own_bos_get_exactly_one():
+    """A chat template whose text already starts with the BOS string (Llama-3-Instruct's
+    `<|begin_of_text|>`) must not get a second BOS from the tokenizer; the reference's Zephyr
+    template has none and gets the tokenizer's usual one."""
+    from distributed_llm_inference_amd.runtime.tokenizer import encode_prompt
+
+    class Tok:
+        bos_token, bos_token_id = "<|begin_of_text|>", 7
+
+        def encode(self, text, add_special_tokens=True):
+            body = [100 + len(text)]
+            if text.startswith(self.bos_token):
+                body = [self.bos_token_id] + body          # the tokenizer maps the literal to its id
+            return ([self.bos_token_id] if add_special_tokens else []) + body
+
+    t = Tok()
+    assert encode_prompt(t, "<|begin_of_text|><|start_header_id|>user").count(7) == 1
+    assert encode_prompt(t, format_chat_prompt("hi")).count(7) == 1
+    b = ByteTokenizer()
+    ids = encode_prompt(b, format_chat_prompt("hi"))
+    assert ids[0] == b.bos_token_id and ids.count(b.bos_token_id) == 1
+    assert encode_prompt(b, "<s>already").count(b.bos_token_id) == 1
