@@ -279,10 +279,13 @@ def main():
         value = tokens / elapsed
         base = baseline_for(a.model)
         p50 = lat[len(lat) // 2] if lat else elapsed / a.steps * 1e3
-        plans = None
+        plans = bound = None
         try:
+            from distributed_llm_inference_amd.models.partition import weak_scaling_bound
             from distributed_llm_inference_amd.parallel.launcher import plans_for
-            plans = [p.describe() for p in plans_for(cfg, spec)]
+            pl = plans_for(cfg, spec)
+            plans = [p.describe() for p in pl]
+            bound = round(weak_scaling_bound(spec, pl), 3)
         except Exception:
             pass
         print(json.dumps({
@@ -298,6 +301,7 @@ def main():
             "config": {"model": spec.name, "global_batch": global_batch, "seq_len": a.prompt_len,
                        "parallelism": f"pp{world}", "micro_batches": cfg.num_micro_batches,
                        "micro_batch_size": cfg.max_batch, "layer_ranges": plans,
+                       "weak_scaling_bound_from_partition": bound,
                        "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": bool(cfg.use_graphs and not a.cpu), "decode_streams": cfg.decode_streams,
                        "backend": rt.ex.backend, "transport": cfg.resolved_transport(), "kv_cache": "fp32" if a.cpu else cfg.kv_dtype}}), flush=True)
     if world > 1:

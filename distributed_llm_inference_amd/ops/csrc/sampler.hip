@@ -12,18 +12,25 @@
 // and the draw uses a counter-based Philox4x32-10 keyed by (seed, step) per row, so a request is
 // reproducible regardless of batching (the reference uses the global unseeded torch RNG).
 //
-// Method: a pivot taken from a sorted 1024-element sample puts a few hundred values above it; one
-// pass over the row collects everything >= pivot into LDS (retry with a moved pivot, then an
-// exact 4 x 8-bit radix select, if the count misses [k, kCap]); bitonic sort of the candidates;
-// cut at the k-th value; block scan for the cumulative mass. Since top-k runs first, top-p only
-// ever touches the <= kCap survivors. Rows must be 16-byte aligned (row stride multiple of 4).
+// Method for 1 <= k <= 1024 (the serving path: k = 50): a pivot taken from a sorted 1024-element
+// sample puts a few hundred values above it; one pass over the row collects everything >= pivot
+// into LDS (retry with a moved pivot, then an exact 4 x 8-bit radix select, if the count misses
+// [k, kCap]); bitonic sort of the candidates; cut at the k-th value; block scan for the cumulative
+// mass. Since top-k runs first, top-p only ever touches the <= kCap survivors.
+// Method for k <= 0 ("no top-k", orchestration.py:150) and k > 1024 on rows longer than 1024: nothing
+// bounds the survivors, so nothing is sorted. The sorted order (value descending, index ascending
+// among equals) is walked implicitly by radix selects over the float keys, weighted by softmax mass:
+// one select finds the entry in which the cumulative mass crosses top_p (everything above it, and
+// the ties up to it, is the nucleus), a second one the entry in which it crosses u x kept mass (the
+// draw), and a scan in index order resolves the tie rank. Exact for any k, top_p and tie pattern.
+// Rows must be 16-byte aligned (row stride multiple of 4).
 #include "common.h"
 #include "launch.h"
 
 namespace dlia {
 
 constexpr int kSampThreads = 1024;
-constexpr int kCap = 1024;            // max candidates kept after top-k (k is clamped to this)
+constexpr int kCap = 1024;            // candidates the sorted path holds in LDS; larger / absent k takes the full-row path
 
 __device__ __forceinline__ unsigned f2key(float f) {
   const unsigned u = __builtin_bit_cast(unsigned, f);
@@ -58,8 +65,238 @@ struct SampleParams {
   float* dbg_probs; int* dbg_ids; int dbg_cap;
 };
 
+
+// ---- exact full-row path (k <= 0 or k > kCap) --------------------------------------------------
+// Softmax masses are carried as 40-bit fixed point (mass 1.0 = 2^40, the row maximum) in 64-bit
+// integers: integer sums do not depend on the order the LDS atomics land in, so the same row and
+// seed always give the same token, and equal logits have exactly equal masses, so a tie group's mass
+// is its count times one member's.
+typedef unsigned long long Q;
+__device__ __forceinline__ Q mass_q(float v, float zmax, float inv_t) {
+  return (Q)(__expf((v - zmax) * inv_t) * 1099511627776.f);
+}
+
+struct FullShared {
+  Q hm[256];              // softmax mass per radix bin
+  unsigned hc[256];       // entries per radix bin
+  unsigned prefix;        // key bits fixed so far
+  Q t_rem;                // target mass still to walk inside the current prefix
+  Q s_above;              // mass of the entries sorted before the selected key
+  unsigned c_above;       // their number
+  Q m_at;                 // mass and number of the entries AT the selected key (after the last pass)
+  unsigned c_at;
+  Q redq[16];
+  float red[16];
+  int redi[16];
+  int found;
+};
+
+__device__ __forceinline__ Q full_block_sum(Q v, FullShared& sh, int lane, int wave) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0) sh.redq[wave] = v;
+  __syncthreads();
+  Q t = 0;
+  for (int w = 0; w < 16; ++w) t += sh.redq[w];
+  return t;
+}
+
+// Walks the entries with key >= max(kfloor, ceil_key) in sorted order (key descending) until the
+// cumulative mass exceeds `target`: leaves in `sh` the key of the entry that contains the target
+// (prefix), the mass and count of everything sorted before that KEY (s_above, c_above) and the mass /
+// count at the key itself (m_at, c_at). Of the tie group at `part_key` only `part_keep` members
+// belong to the set (drop = the others' count; their mass leaves the bin they fall in). A target at
+// or beyond the total mass selects the smallest key present.
+__device__ void full_weighted_select(const float* row, int V, float zmax, float inv_t, unsigned kfloor, unsigned part_key,
+                                     unsigned part_drop, Q part_q, unsigned ceil_key, Q target, FullShared& sh,
+                                     int tid, int lane, int wave) {
+  if (tid == 0) { sh.prefix = 0u; sh.t_rem = target; sh.s_above = 0; sh.c_above = 0u; }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) { sh.hm[tid] = 0; sh.hc[tid] = 0u; }
+    __syncthreads();
+    const unsigned prefix = sh.prefix;
+    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = tid; i < V; i += kSampThreads) {
+      const float v = row[i];
+      const unsigned key = f2key(v);
+      if (key < kfloor || key < ceil_key || (key & himask) != (prefix & himask)) continue;
+      atomicAdd(&sh.hm[(key >> shift) & 255u], mass_q(v, zmax, inv_t));
+      atomicAdd(&sh.hc[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0 && part_drop > 0u && (part_key & himask) == (prefix & himask)) {
+      sh.hm[(part_key >> shift) & 255u] -= (Q)part_drop * part_q;
+      sh.hc[(part_key >> shift) & 255u] -= part_drop;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // lane owns bins 4 lane .. 4 lane + 3; suffix sums from the top bin down
+      Q m[4]; unsigned c[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { m[b] = sh.hm[4 * lane + b]; c[b] = sh.hc[4 * lane + b]; }
+      const Q mine = m[0] + m[1] + m[2] + m[3];
+      const unsigned cmine = c[0] + c[1] + c[2] + c[3];
+      Q suf = mine; unsigned csuf = cmine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const Q t = __shfl_down(suf, o, 64); const unsigned ct = __shfl_down(csuf, o, 64);
+        if (lane + o < 64) { suf += t; csuf += ct; }
+      }
+      const Q t_rem = sh.t_rem;
+      const Q above = suf - mine;
+      const unsigned cabove = csuf - cmine;
+      bool hit = cmine > 0u && above <= t_rem && t_rem < suf;
+      unsigned long long hits = __ballot(hit);
+      if (hits == 0ull) {                         // target at or beyond the total: the smallest key present
+        const unsigned long long nonempty = __ballot(cmine > 0u);
+        hit = nonempty != 0ull && lane == (int)__builtin_ctzll(nonempty);
+        hits = __ballot(hit);
+      }
+      const int first = hits ? 63 - (int)__builtin_clzll(hits) : -1;       // the top-most hit
+      if (lane == first) {
+        Q acc = above; unsigned cacc = cabove; int bin = -1;
+#pragma unroll
+        for (int b = 3; b >= 0; --b) {
+          if (bin < 0 && c[b] > 0u) {
+            const bool last_nonempty = (b == 0) || (c[0] + (b > 1 ? c[1] : 0u) + (b > 2 ? c[2] : 0u) == 0u);
+            if (t_rem < acc + m[b] || last_nonempty) bin = b;
+            else { acc += m[b]; cacc += c[b]; }
+          }
+        }
+        if (bin < 0) bin = 0;
+        sh.prefix = prefix | ((unsigned)(4 * lane + bin) << shift);
+        sh.s_above += acc;
+        sh.c_above += cacc;
+        sh.t_rem = t_rem > acc ? t_rem - acc : 0;
+        sh.m_at = m[bin]; sh.c_at = c[bin];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// The whole draw for one row; returns (through p.out[r]) the sampled token. `k` <= 0: no top-k.
+__device__ void sample_full_row(const SampleParams& p, int r, const float* row, int V, float temp, int k, float top_p,
+                                FullShared& sh, unsigned* hist, unsigned& s_prefix, unsigned& s_krem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv_t = 1.f / temp;
+  // ---- top-k floor: exact key of the k-th largest value (ties at it survive) -----------------
+  unsigned kfloor = 0u;
+  if (k > 0 && k < V) {
+    if (tid == 0) { s_prefix = 0u; s_krem = (unsigned)k; }
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (tid < 256) hist[tid] = 0u;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = tid; i < V; i += kSampThreads) {
+        const unsigned key = f2key(row[i]);
+        if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const unsigned mine = h0 + h1 + h2 + h3;
+        unsigned suf = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned t = __shfl_down(suf, o, 64);
+          if (lane + o < 64) suf += t;
+        }
+        const unsigned krem = s_krem;
+        const unsigned above = suf - mine;
+        if (above < krem && krem <= suf) {
+          unsigned cnt = above; int bin;
+          if (cnt + h3 >= krem) bin = 3;
+          else { cnt += h3; if (cnt + h2 >= krem) bin = 2;
+            else { cnt += h2; if (cnt + h1 >= krem) bin = 1; else { cnt += h1; bin = 0; } } }
+          s_prefix = prefix | ((unsigned)(4 * lane + bin) << shift);
+          s_krem = krem - cnt;
+        }
+      }
+      __syncthreads();
+    }
+    kfloor = s_prefix;
+  }
+  // ---- maximum and total mass of the surviving entries ----------------------------------------
+  float zmax = -__builtin_inff();
+  for (int i = tid; i < V; i += kSampThreads) zmax = fmaxf(zmax, row[i]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64));
+  __syncthreads();
+  if (lane == 0) sh.red[wave] = zmax;
+  __syncthreads();
+  for (int w = 0; w < 16; ++w) zmax = fmaxf(zmax, sh.red[w]);
+  Q zl = 0; Q nl = 0;
+  for (int i = tid; i < V; i += kSampThreads) {
+    const float v = row[i];
+    if (f2key(v) >= kfloor) { zl += mass_q(v, zmax, inv_t); ++nl; }
+  }
+  const Q Z = full_block_sum(zl, sh, lane, wave);
+  const int nsurv = (int)full_block_sum(nl, sh, lane, wave);
+  // ---- top-p: the entry in which the cumulative mass crosses top_p * Z ends the nucleus -----------
+  // (an entry is kept iff the mass sorted before it is <= top_p * Z: orchestration.py:159-164 removes
+  // the entries whose cumulative probability exceeds top_p, shifted by one so the crossing entry stays)
+  unsigned bkey = kfloor; Q kept_mass = Z, part_q = 0; unsigned part_key = 0xFFFFFFFFu, part_drop = 0u; int nkeep = nsurv;
+  bool cut = false;
+  if (top_p < 1.f) {
+    const Q P = (Q)((double)top_p * (double)Z);
+    full_weighted_select(row, V, zmax, inv_t, kfloor, 0xFFFFFFFFu, 0u, 0, 0u, P, sh, tid, lane, wave);
+    const Q q_b = sh.c_at ? sh.m_at / (Q)sh.c_at : 0;                       // one boundary entry's mass (ties are exact)
+    // a tie with rank t (index order) is kept iff s_above + t q_b <= P
+    Q tstar = q_b > 0 ? sh.t_rem / q_b : (Q)sh.c_at - 1;
+    if (tstar > (Q)sh.c_at - 1) tstar = (Q)sh.c_at - 1;
+    const unsigned kept_ties = (unsigned)tstar + 1u;
+    bkey = sh.prefix; cut = true;
+    kept_mass = sh.s_above + (Q)kept_ties * q_b;
+    nkeep = (int)sh.c_above + (int)kept_ties;
+    if (kept_ties < sh.c_at) { part_key = bkey; part_drop = sh.c_at - kept_ties; part_q = q_b; }
+    __syncthreads();
+  }
+  // ---- the draw: the entry in which the kept cumulative mass crosses u * kept_mass ----------------
+  const float u = philox_uniform(p.seeds ? p.seeds[r] : 0ull, p.steps ? (unsigned)p.steps[r] : 0u);
+  Q target = (Q)((double)u * (double)kept_mass);
+  if (kept_mass > 0 && target >= kept_mass) target = kept_mass - 1;
+  full_weighted_select(row, V, zmax, inv_t, kfloor, part_key, part_drop, part_q, cut ? bkey : 0u, target, sh, tid, lane, wave);
+  const unsigned dkey = sh.prefix;
+  const Q q_d = sh.c_at ? sh.m_at / (Q)sh.c_at : 0;
+  Q tr = q_d > 0 ? sh.t_rem / q_d : 0;
+  if (sh.c_at && tr > (Q)sh.c_at - 1) tr = (Q)sh.c_at - 1;
+  const int trank = (int)tr;                   // rank, in index order, among the members at the drawn key
+  __syncthreads();
+  // ---- the trank-th entry, in index order, among those with key == dkey ---------------------------
+  if (tid == 0) sh.found = 0;
+  __syncthreads();
+  int seen = 0;
+  for (int base = 0; base < V; base += kSampThreads) {
+    const int i = base + tid;
+    const bool eq = i < V && f2key(row[i]) == dkey;
+    const unsigned long long bal = __ballot(eq);
+    if (lane == 0) sh.redi[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) before += sh.redi[w]; total += sh.redi[w]; }
+    const int my = seen + before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (eq && my == trank) { p.out[r] = i; sh.found = 1; }
+    seen += total;
+    __syncthreads();
+    if (sh.found || seen > trank) break;
+  }
+  if (p.dbg_probs && tid == 0) {
+    // diagnostics of this path: ids[0] = -2 (marker), ids[1] = entries kept, probs[0] = kept mass / survivor mass
+    for (int i = 0; i < p.dbg_cap; ++i) { p.dbg_probs[(long)r * p.dbg_cap + i] = 0.f; p.dbg_ids[(long)r * p.dbg_cap + i] = -1; }
+    p.dbg_ids[(long)r * p.dbg_cap] = -2;
+    if (p.dbg_cap > 1) p.dbg_ids[(long)r * p.dbg_cap + 1] = nkeep;
+    p.dbg_probs[(long)r * p.dbg_cap] = (float)((double)kept_mass / (double)Z);
+  }
+}
+
 __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   __shared__ unsigned hist[256];
+  __shared__ FullShared fsh;
   __shared__ unsigned s_prefix, s_krem, s_ncand;
   __shared__ float cval[kCap];
   __shared__ int cidx[kCap];
@@ -109,9 +346,12 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   }
 
   int k = p.top_k ? p.top_k[r] : 0;
-  if (k <= 0 || k > kCap) k = kCap;
-  if (k > V) k = V;
   const float top_p = p.top_p ? p.top_p[r] : 1.f;
+  if (V > kCap && (k <= 0 || k > kCap)) {          // no top-k, or more survivors than LDS holds: exact full-row walk
+    sample_full_row(p, r, row, V, temp, k, top_p, fsh, hist, s_prefix, s_krem);
+    return;
+  }
+  if (k <= 0 || k > V) k = V;                      // (V <= kCap: every entry is a candidate)
   if (tid == 0) s_ncand = 0u;
 
   // ---- candidate gathering ----------------------------------------------------------------
@@ -236,6 +476,11 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
     }
   }
   __syncthreads();
+  if (s_ncand > (unsigned)kCap) {                  // ties at the k-th value: more survivors than LDS holds
+    __syncthreads();
+    sample_full_row(p, r, row, V, temp, k, top_p, fsh, hist, s_prefix, s_krem);
+    return;
+  }
   }
   int ncand = min((int)s_ncand, kCap);
   __syncthreads();

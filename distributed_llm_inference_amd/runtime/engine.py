@@ -633,6 +633,17 @@ class Engine:
         r._set_done()
 
     # ---- introspection -----------------------------------------------------------------------
+    def wait_idle(self, timeout_s: float = 5.0) -> bool:
+        """Blocks until no request is waiting or running and every finished row has been retired (a
+        request is marked done before the scheduler's next tick gives its KV blocks back)."""
+        deadline = time.perf_counter() + timeout_s
+        while time.perf_counter() < deadline:
+            st = self.snapshot()
+            if st["waiting"] == 0 and st["running"] == 0 and all(r is None for mb in self.mbs for r in mb.rows):
+                return True
+            time.sleep(0.002)
+        return False
+
     def snapshot(self) -> Dict:
         lat = sorted(self.latencies)
         p = lambda q: lat[min(len(lat) - 1, int(q * len(lat)))] * 1e3 if lat else None

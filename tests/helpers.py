@@ -70,3 +70,31 @@ def step(slots, q_lens, ctx_lens, token_ids=None, sample=None, temperature=0.0, 
                      table_slots=list(tables.keys()) if tables else [],
                      table_blocks=[list(v) for v in tables.values()] if tables else [],
                      token_ids=list(token_ids) if token_ids is not None else None)
+
+
+def divergences_are_near_ties(ref_stage, prompts, got, want, rel=0.05, abs_tol=0.02):
+    """Greedy decoding in bf16 may pick another token than the fp32 reference where two logits are
+    nearly tied, after which the sequences differ for good. This checks that EVERY first divergence
+    is such a near-tie: the fp32 reference, evaluated on the common prefix, must score the token the
+    engine chose within `rel` x max|logit| + `abs_tol` of its own choice. Returns the number of
+    diverged sequences; raises AssertionError with the gap otherwise."""
+    diverged = 0
+    for k, (p, g, w) in enumerate(zip(prompts, got, want)):
+        n = 0
+        while n < min(len(g), len(w)) and g[n] == w[n]:
+            n += 1
+        if n == min(len(g), len(w)):
+            assert len(g) == len(w), f"sequence {k}: lengths differ without a token mismatch"
+            continue
+        diverged += 1
+        ctx = list(p) + list(w[:n])
+        slot = 10_000 + k
+        b = step([slot], [len(ctx)], [0])
+        logits = ref_stage.forward(b, torch.tensor(ctx, dtype=torch.int32))[0].float().cpu()
+        ref_stage.release([slot])
+        assert int(logits.argmax()) == w[n], f"sequence {k}: the reference does not reproduce its own token at {n}"
+        gap = float(logits[w[n]] - logits[g[n]])
+        tol = rel * float(logits.abs().max()) + abs_tol
+        assert gap <= tol, (f"sequence {k} diverges at token {n}: engine chose {g[n]}, reference {w[n]}, "
+                            f"reference logit gap {gap:.4f} > tolerance {tol:.4f}")
+    return diverged

@@ -251,6 +251,7 @@ def test_kv_blocks_grow_on_demand_and_many_more_requests_than_the_pool_holds_all
     pipe = LocalPipeline(cfg(max_seq_len=256, kv_blocks=16))
     try:
         got = run(pipe, ps, greedy(40))
+        pipe.engine.wait_idle()
         snap = pipe.engine.snapshot()
     finally:
         pipe.close()
@@ -274,6 +275,7 @@ def test_preemption_recomputes_and_keeps_the_tokens_identical():
     pipe = LocalPipeline(cfg(max_seq_len=256, num_micro_batches=1, max_batch=8, kv_blocks=max(6, need_all // 2)))
     try:
         got = run(pipe, ps, greedy(70))
+        pipe.engine.wait_idle()
         snap = pipe.engine.snapshot()
     finally:
         pipe.close()

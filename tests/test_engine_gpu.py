@@ -36,6 +36,7 @@ def run(c, ps, params, timeout=120, executors=None):
     try:
         reqs = [pipe.engine.submit(p, params) for p in ps]
         outs = [r.wait(timeout).output for r in reqs]
+        pipe.engine.wait_idle()       # a request is done before the scheduler's next tick frees its blocks
         snap = pipe.engine.snapshot()
     finally:
         pipe.close()
@@ -82,15 +83,11 @@ def test_gpu_engine_tracks_torch_backend():
                       max_seq_len=c.max_seq_len)
     gpu, _ = run(c, ps, greedy(12), executors=[gpu_ex])
     cpu, _ = run(cfg(backend="torch", device="cpu"), ps, greedy(12), executors=[ref_ex])
-    first_ok = sum(g[0] == c[0] for g, c in zip(gpu, cpu))
-    assert first_ok >= len(ps) - 1
-    prefix = []
-    for g, c in zip(gpu, cpu):
-        n = 0
-        while n < len(g) and g[n] == c[n]:
-            n += 1
-        prefix.append(n)
-    assert sum(prefix) >= 0.5 * 12 * len(ps), prefix
+    from helpers import divergences_are_near_ties
+    # every sequence either matches the fp32 reference token for token, or first differs where the
+    # reference itself scores the two tokens within bf16 noise of each other
+    assert all(len(o) == 12 for o in gpu)
+    assert divergences_are_near_ties(ref_ex, ps, gpu, cpu) <= len(ps) // 2
 
 
 def test_long_prompts_chunked_by_the_scheduler_track_torch_backend():
@@ -117,15 +114,8 @@ def test_long_prompts_chunked_by_the_scheduler_track_torch_backend():
     assert snap["fatal"] is None
     cpu, _ = run(cfg(prefill_chunk=96, backend="torch", device="cpu"), ps, greedy(10), executors=[ref_ex])
     assert all(len(o) == 10 for o in gpu)
-    first_ok = sum(a[0] == b[0] for a, b in zip(gpu, cpu))
-    assert first_ok >= len(ps) - 1, (gpu, cpu)
-    prefix = []
-    for a, b in zip(gpu, cpu):
-        n = 0
-        while n < len(a) and a[n] == b[n]:
-            n += 1
-        prefix.append(n)
-    assert sum(prefix) >= 0.5 * 10 * len(ps), prefix
+    from helpers import divergences_are_near_ties
+    assert divergences_are_near_ties(ref_ex, ps, gpu, cpu) <= len(ps) // 2
 
 
 def test_sampled_generation_is_reproducible_and_stops_at_cap():
@@ -164,17 +154,19 @@ def test_checkpoint_directory_on_gpu_matches_transformers(tmp_path):
     ps = prompts(4, seed=8)
     got, _ = run(cfg(model=path, pp_size=2, num_micro_batches=2), ps, greedy(10))
     hf = hf_model_from(spec, seed=9).to(torch.bfloat16).float()
-    agree = 0
+    # token for token against transformers on the same (bf16-rounded) weights; a mismatch is only
+    # accepted where transformers itself scores the engine's token within bf16 noise of its own
     for p, g in zip(ps, got):
         ids = torch.tensor([p])
         with torch.no_grad():
-            for t in g:
-                nxt = int(hf(ids).logits[0, -1].argmax())
+            for n, t in enumerate(g):
+                logits = hf(ids).logits[0, -1].float()
+                nxt = int(logits.argmax())
                 if nxt != t:
+                    gap = float(logits[nxt] - logits[t])
+                    assert gap <= 0.05 * float(logits.abs().max()) + 0.02, (n, t, nxt, gap)
                     break
-                agree += 1
                 ids = torch.cat([ids, torch.tensor([[nxt]])], 1)
-    assert agree >= 0.6 * 10 * len(ps), agree
 
 
 @pytest.mark.parametrize("model,dtype", [("tiny-gpt2-gpu-test", "bf16"), (MODEL, "fp8"), (MODEL, "fp8w")])

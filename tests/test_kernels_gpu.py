@@ -381,7 +381,7 @@ def test_gemm_pingpong_shapes(K, shape):
         K.large_gemm_kernel(prev)
 
 
-@pytest.mark.parametrize("shape", [(1024, 4096, 4096, 2), (1024, 6144, 4096, 0), (1024, 4096, 14336, 2), (512, 4096, 4096, 3),
+@pytest.mark.parametrize("shape", [(1024, 4096, 4096, 2), (512, 6144, 4096, 0), (1024, 4096, 14336, 2), (512, 4096, 4096, 3),
                                    (700, 1152, 2048, 4), (300, 384, 1024, 5)])
 def test_gemm_pingpong_split_k_inside_the_launch(K, shape):
     """Shapes with fewer 256 x 256 tiles than CUs split K over neighbouring workgroups; the last one

@@ -166,6 +166,10 @@ def test_spec_roundtrip_through_hf_config(tmp_path):
         ModelSpec.from_pretrained("no/such-model")
 
 
+def cost_of(plans, head):
+    return [p.num_layers + (head if p.has_head else 0.0) for p in plans]
+
+
 def test_partitioner():
     assert even_split(22, 2) == [(0, 11), (11, 22)]           # the reference's split (Worker1.py:27-28)
     assert even_split(32, 8) == [(i * 4, i * 4 + 4) for i in range(8)]
@@ -176,9 +180,14 @@ def test_partitioner():
     s8 = BUILTIN_SPECS["llama-3-8b"]
     b = balanced_split(s8, 4)
     assert b[0][0] == 0 and b[-1][1] == 32 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
-    head = s8.head_param_count() / s8.layer_param_count()
+    from distributed_llm_inference_amd.models.partition import head_cost_layers, stage_costs, weak_scaling_bound
+    head = head_cost_layers(s8)
+    assert 1.3 < head < 1.7                                   # 2.4 layers' worth of parameters, ~1.5 layers of time
     cost = [e - a + (head if i == 3 else 0) for i, (a, e) in enumerate(b)]
     assert max(cost) <= 9.0 + 1e-9 and (b[-1][1] - b[-1][0]) < 8     # the lm_head stage carries fewer layers
+    p8 = make_plans(s8, 8)
+    assert stage_costs(s8, p8) == cost_of(p8, head) and max(stage_costs(s8, p8)) == 5.0
+    assert abs(weak_scaling_bound(s8, p8) - (32 + head) / 40) < 1e-9 and weak_scaling_bound(s8, make_plans(s8, 1)) == 1.0
     plans = make_plans(BUILTIN_SPECS["tinyllama"], 2, mode="even")
     assert plans[0].has_embed and not plans[0].has_head and plans[1].has_head and plans[1].describe() == "11-22"
     with pytest.raises(ValueError):
