@@ -75,6 +75,12 @@ def parse():
     return ap.parse_args()
 
 
+def metric_model(name: str) -> str:
+    """'meta-llama/Meta-Llama-3-8B' -> 'Llama-3-8B' (the headline metric names the model)."""
+    short = name.split("/")[-1]
+    return short[5:] if short.startswith("Meta-") else short
+
+
 def baseline_for(model: str):
     """Throughput (tok/s) of the reference's own CPU / JSON-over-HTTP path for this model, as measured
     by bench/reference_baseline.py and stored in bench/baseline_numbers.json; None if not measured."""
@@ -204,15 +210,20 @@ def _deadline(seconds: float):
 
 def _fit_batch(a, nmb: int, max_seq: int, world: int) -> int:
     """The KV cache holds every in-flight sequence for prompt + warm-up + timed steps. A long run
-    (--steps in the hundreds) at 2 x 1024 sequences per GPU would ask for more than the device has:
-    halve the micro-batch until the largest stage's share fits in 60 % of device memory, and say so
-    (the size used is reported in the JSON line's config)."""
+    (--steps in the hundreds) at 2 x 1024 sequences per GPU, or a 70B model on one GPU, would ask
+    for more than the device has: halve the micro-batch until the largest stage's share fits in 85 %
+    of what its weights leave, and say so (the size used is reported in the JSON line's config)."""
     from distributed_llm_inference_amd.parallel.launcher import plans_for, resolve_spec
     cfg = EngineConfig(model=a.model, pp_size=world, partition=a.partition)
     spec = resolve_spec(cfg)
-    layers = max(p.layer_end - p.layer_start for p in plans_for(cfg, spec))
+    plans = plans_for(cfg, spec)
+    layers = max(p.layer_end - p.layer_start for p in plans)
+    wbytes = 1 if a.dtype in ("fp8", "fp8w") else 2
+    weights = max((p.layer_end - p.layer_start) * spec.layer_param_count()
+                  + (spec.embed_param_count() if p.has_embed else 0) + (spec.head_param_count() if p.has_head else 0)
+                  for p in plans) * wbytes
     idx = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
-    budget = 0.6 * torch.cuda.get_device_properties(idx).total_memory
+    budget = 0.85 * (torch.cuda.get_device_properties(idx).total_memory - weights - (8 << 30))
     batch = a.batch
     while batch > 64 and nmb * batch * max_seq * spec.kv_bytes_per_token_per_layer(1 if a.kv_dtype == "fp8" else 2) * layers > budget:
         batch //= 2
@@ -244,6 +255,10 @@ def main():
                        backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype, decode_streams=a.decode_streams,
                        transport="gloo" if a.cpu else a.transport, kv_dtype="bf16" if a.cpu else a.kv_dtype)
     rank, world, rt, board, spec, cfg = attach_distributed(cfg)
+    need = cfg.num_micro_batches * cfg.max_batch * ((cfg.max_seq_len + 31) // 32)
+    have = getattr(rt.ex, "num_blocks", need)
+    if have < need:                                  # the static block tables below index slot x blocks_per_seq
+        raise SystemExit(f"bench.py: the KV pool holds {have} blocks, the schedule needs {need}; use a smaller --batch")
     if rank != 0:
         stage_main(rt)
         t = rt.barrier_times
@@ -289,7 +304,7 @@ def main():
         except Exception:
             pass
         print(json.dumps({
-            "metric": "output tokens/sec (whole node), Llama-3-8B layer-split PP=N",
+            "metric": f"output tokens/sec (whole node), {metric_model(spec.name)} layer-split PP=N",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (round(value / base, 1) if base else None),

@@ -27,29 +27,31 @@ def free_port():
 
 
 async def run_load(url, clients, requests, max_tokens, prompt_words, timeout):
-    import httpx
+    """`clients` connections, each posting its share of `requests` one after the other (closed loop).
+    aiohttp: with hundreds of open connections the client must not be what is measured."""
+    import aiohttp
     lat, toks, fails = [], 0, 0
-    sem = asyncio.Semaphore(clients)
-    limits = httpx.Limits(max_connections=clients, max_keepalive_connections=clients)
-    async with httpx.AsyncClient(limits=limits, timeout=timeout) as cl:
-        async def one(i):
+    todo = iter(range(requests))
+    conn = aiohttp.TCPConnector(limit=clients, force_close=False)
+    async with aiohttp.ClientSession(connector=conn, timeout=aiohttp.ClientTimeout(total=timeout)) as cl:
+        async def client():
             nonlocal toks, fails
-            body = {"prompt": " ".join(f"w{(i * 7 + k) % 997}" for k in range(prompt_words)), "max_tokens": max_tokens,
-                    "temperature": 0.7}
-            async with sem:
+            for i in todo:
+                body = {"prompt": " ".join(f"w{(i * 7 + k) % 997}" for k in range(prompt_words)), "max_tokens": max_tokens,
+                        "temperature": 0.7}
                 t0 = time.perf_counter()
                 try:
-                    r = await cl.post(url + "/generate", json=body)
-                    d = r.json()
-                    if r.status_code == 200 and d.get("status") == "success":
-                        toks += int(d["tokens_generated"])
-                        lat.append(time.perf_counter() - t0)
-                    else:
-                        fails += 1
+                    async with cl.post(url + "/generate", json=body) as r:
+                        d = await r.json()
+                        if r.status == 200 and d.get("status") == "success":
+                            toks += int(d["tokens_generated"])
+                            lat.append(time.perf_counter() - t0)
+                        else:
+                            fails += 1
                 except Exception:
                     fails += 1
         t0 = time.perf_counter()
-        await asyncio.gather(*(one(i) for i in range(requests)))
+        await asyncio.gather(*(client() for _ in range(clients)))
         wall = time.perf_counter() - t0
     lat.sort()
     pick = lambda q: round(lat[min(len(lat) - 1, int(q * len(lat)))] * 1e3, 1) if lat else None
@@ -75,6 +77,9 @@ def main():
     ap.add_argument("--max-tokens", type=int, default=32)
     ap.add_argument("--prompt-words", type=int, default=16)
     ap.add_argument("--timeout", type=float, default=600.0)
+    ap.add_argument("--transport", default="auto", help="stage transport of the spawned orchestrator (gloo: stages may share one GPU)")
+    ap.add_argument("--kv-dtype", default="bf16")
+    ap.add_argument("--show-one", action="store_true", help="first print the whole JSON answer of one /generate")
     a = ap.parse_args()
     proc = None
     url = a.url
@@ -85,7 +90,8 @@ def main():
                "--device", a.device, "--pp-size", str(a.pp_size), "--max-batch", str(a.batch),
                "--num-micro-batches", str(a.micro_batches), "--max-seq-len", str(a.max_seq_len),
                "--max-tokens-cap", str(max(a.max_tokens, 32)), "--host", "127.0.0.1", "--port", str(port),
-               "--server", a.server]
+               "--server", a.server, "--transport", a.transport, "--kv-dtype", a.kv_dtype]
+        t_spawn = time.time()
         proc = subprocess.Popen(cmd, cwd=ROOT, start_new_session=True)
         import httpx
         t0 = time.time()
@@ -99,9 +105,19 @@ def main():
                 raise SystemExit("orchestrator did not come up")
             time.sleep(0.5)
     try:
+        if proc is not None:
+            print(json.dumps({"startup_s": round(time.time() - t_spawn, 1)}), flush=True)
+        if a.show_one:
+            import httpx
+            t0 = time.perf_counter()
+            r = httpx.post(url + "/generate", json={"prompt": "Explain pipeline parallel inference in one sentence.",
+                                                    "max_tokens": a.max_tokens, "temperature": 0.7}, timeout=a.timeout)
+            print(json.dumps({"one_generate": r.json(), "http_status": r.status_code,
+                              "client_wall_s": round(time.perf_counter() - t0, 3),
+                              "workers": httpx.get(url + "/workers", timeout=30).json()}), flush=True)
         asyncio.run(run_load(url, min(a.clients, 8), min(a.requests, 16), a.max_tokens, a.prompt_words, a.timeout))   # warm-up
         out = asyncio.run(run_load(url, a.clients, a.requests, a.max_tokens, a.prompt_words, a.timeout))
-        out.update({"server": a.server if proc else "external", "model": a.model, "dtype": a.dtype, "pp_size": a.pp_size,
+        out.update({"server": a.server if proc else "external", "model": a.model, "dtype": a.dtype, "pp_size": a.pp_size, "transport": a.transport,
                     "micro_batch": a.batch, "micro_batches": a.micro_batches})
         print(json.dumps(out))
     finally:

@@ -31,11 +31,22 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"])
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--isolate", action="store_true", help="stage processes as children of this one (what `serve` does on GPUs)")
+    ap.add_argument("--max-seq-len", type=int, default=0)
+    ap.add_argument("--closed-loop", type=int, default=0, metavar="CLIENTS",
+                    help="CLIENTS requests outstanding at any time, each completion submits the next (default: all at t = 0)")
+    ap.add_argument("--admit-fill", type=float, default=None, help="EngineConfig.admit_fill_fraction")
+    ap.add_argument("--admit-wait-ms", type=float, default=None, help="EngineConfig.admit_max_wait_ms")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="closed loop: spread the first CLIENTS arrivals over this long")
     a = ap.parse_args()
     cfg = EngineConfig(model=a.model, pp_size=a.pp_size, max_batch=a.batch, num_micro_batches=a.micro_batches,
-                       max_seq_len=((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=2048, dtype=a.dtype, kv_dtype=a.kv_dtype,
+                       max_seq_len=a.max_seq_len or ((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=2048, isolate=a.isolate, dtype=a.dtype, kv_dtype=a.kv_dtype,
                        device="cpu" if a.cpu else "auto", backend="torch" if a.cpu else "auto",
                        transport="loopback" if a.cpu else "auto")
+    if a.admit_fill is not None:
+        cfg.admit_fill_fraction = a.admit_fill
+    if a.admit_wait_ms is not None:
+        cfg.admit_max_wait_ms = a.admit_wait_ms
     pipe = make_pipeline(cfg)
     eng = pipe.engine
     g = torch.Generator().manual_seed(0)
@@ -48,9 +59,34 @@ def main():
         for r in warm:
             r.wait(600)
         t0 = time.perf_counter()
-        reqs = [eng.submit(p, sp) for p in prompts]
-        for r in reqs:
-            r.wait(1800)
+        if a.closed_loop:
+            import threading
+            lock, reqs, nxt, done = threading.Lock(), [], [0], threading.Event()
+
+            def launch(_=None):
+                with lock:
+                    i = nxt[0]
+                    if i >= len(prompts):
+                        if all(r.finished or r.state == "failed" for r in reqs):
+                            done.set()
+                        return
+                    nxt[0] += 1
+                    r = eng.submit(prompts[i], sp)
+                    reqs.append(r)
+                r.add_done_callback(launch)
+
+            for c in range(min(a.closed_loop, len(prompts))):
+                launch()
+                if a.stagger_ms:
+                    time.sleep(a.stagger_ms / 1e3 / a.closed_loop)
+            while not done.wait(0.05):
+                with lock:
+                    if nxt[0] >= len(prompts) and all(r.finished or r.state == "failed" for r in reqs):
+                        break
+        else:
+            reqs = [eng.submit(p, sp) for p in prompts]
+            for r in reqs:
+                r.wait(1800)
         dt = time.perf_counter() - t0
     finally:
         snap = eng.snapshot()
@@ -64,7 +100,9 @@ def main():
                       "output_tok_per_s": round(out_tokens / dt, 1), "requests_per_s": round(a.requests / dt, 2),
                       "ttft_ms_p50": q(ttft, 0.5), "ttft_ms_p99": q(ttft, 0.99), "tpot_ms_p50": q(tpot, 0.5),
                       "tpot_ms_p99": q(tpot, 0.99), "recompositions": snap.get("recompositions"),
-                      "config": {"max_batch": a.batch, "micro_batches": a.micro_batches, "pp": a.pp_size, "dtype": a.dtype, "kv_dtype": a.kv_dtype}}))
+                      "config": {"max_batch": a.batch, "micro_batches": a.micro_batches, "pp": a.pp_size, "dtype": a.dtype, "kv_dtype": a.kv_dtype,
+                                 "isolate": a.isolate, "closed_loop_clients": a.closed_loop, "stagger_ms": a.stagger_ms},
+                      "steps": {k: snap.get(k) for k in ("prefill_steps", "decode_steps", "preemptions")}}))
 
 
 if __name__ == "__main__":

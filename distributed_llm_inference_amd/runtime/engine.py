@@ -348,7 +348,7 @@ class Engine:
 
         if mb.state == "steady":
             live = mb.live()
-            waiting_fits = bool(self.waiting) and (mb.free_rows() + mb.dead_rows() > 0) and self._could_admit()
+            waiting_fits = self._worth_stopping_for(mb)
             if (not live or waiting_fits or mb.dead_rows() * 2 >= max(1, len(live) + mb.dead_rows())
                     or (mb.dead_rows() > 0 and not self._static_decode)):
                 mb.state = "draining"
@@ -418,6 +418,19 @@ class Engine:
         if gone:
             self.stats["recompositions"] += 1
             self._dispatch(control(KIND_RELEASE, gone))
+
+    def _worth_stopping_for(self, mb: _MicroBatch) -> bool:
+        """Should this running micro-batch be recomposed to take waiting requests in? Yes when they
+        would fill a worthwhile share of its rows, or when the oldest has waited long enough."""
+        if not self.waiting:
+            return False
+        room = mb.free_rows() + mb.dead_rows()
+        if room <= 0 or not self._could_admit():
+            return False
+        fill = min(len(self.waiting), room)
+        if fill >= max(1, int(self.cfg.admit_fill_fraction * self.cfg.max_batch)):
+            return True
+        return (time.perf_counter() - self.waiting[0].t_arrival) * 1e3 >= self.cfg.admit_max_wait_ms
 
     # ---- KV blocks: admission, growth, preemption ----------------------------------------------
     def _could_admit(self) -> bool:
