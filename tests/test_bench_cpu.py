@@ -102,6 +102,7 @@ def test_micro_batch_shrinks_when_the_kv_cache_would_not_fit(monkeypatch):
     assert fit(32, 1) == 1024 and fit(32, 8) == 1024        # the driver's default fits at every N
     assert fit(1000, 1) == 512                              # 2 x 1024 x 1152 tokens x 128 KiB = 309 GB does not
     assert fit(1000, 8) < 1024
-    # 70B on one GPU: 141 GB of bf16 weights leave room for 2 x 1024 x 192 tokens x 320 KiB, not for 2 x 1024 x 352
-    assert fit(32, 1, "llama-3-70b") == 1024 and fit(200, 1, "llama-3-70b") == 512
-    assert fit(200, 1, "llama-3-70b", "fp8") == 1024
+    # 70B on one GPU: 141 GB of bf16 weights leave room for 2 x 1024 x 192 tokens x 320 KiB, not for 2 x 1024 x 256;
+    # 70 GB of e4m3 weights do leave room for that
+    assert fit(32, 1, "llama-3-70b") == 1024 and fit(100, 1, "llama-3-70b") == 512
+    assert fit(100, 1, "llama-3-70b", "fp8") == 1024
