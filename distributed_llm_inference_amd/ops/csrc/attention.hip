@@ -4,7 +4,9 @@
 // further down takes chunks of more than 128 query columns per sequence): a work item is
 // (sequence b, kv head, query tile, kv split) and is owned by one 4-wave workgroup whose waves
 // interleave the item's KV blocks and merge their (m, l, O) through LDS once at the end — the
-// main loop has no LDS traffic and no barriers.
+// main loop has no LDS traffic and no barriers. paged_attn_lean_kernel is the same body with ONE
+// wave per item, for decode steps with a thousand items or more: no merge, no uneven block counts
+// between waves, 129 registers, so three waves per SIMD hide each other's load latency.
 // The wave's MFMA columns are "query columns" c = (position-in-tile, head-in-GQA-group): all
 // query heads that share a kv head ride in the same MFMA, so K/V are read once per group.
 //
@@ -55,16 +57,19 @@ struct AttnParams {
 
 constexpr float kNegInf = -__builtin_inff();
 
-template <int D, int NT, bool KV8>
-__global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
+// NW = waves per work item: 4 interleave the item's KV blocks and merge at the end (few items, long
+// contexts); 1 walks all of them alone with no LDS and no barrier (decode over thousands of
+// (sequence, kv head) items, where a 160-token context is 5 blocks and 4 waves would take 2, 1, 1, 1).
+template <int D, int NT, bool KV8, int NW, bool PF>
+__device__ __forceinline__ void paged_attn_body(const AttnParams& p) {
   constexpr int KS = D / 32;      // MFMA k-steps over the head dim (QK^T)
   constexpr int DT = D / 16;      // 16-row tiles of the head dim (PV)
   constexpr int NC = NT * 16;     // query columns per workgroup
-  constexpr bool PREFETCH = NT == 1;   // decode: next block's K/V in flight while this one is used
+  constexpr bool PREFETCH = NT == 1 && PF;   // decode: next block's K/V in flight while this one is used
   // LDS: per wave its (m, l) per lane and its O accumulators, merged by the 4 waves at the end
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, l15 = lane & 15, quad = lane >> 4;
-  const int wave = threadIdx.x >> 6;
+  const int wave = NW == 1 ? 0 : threadIdx.x >> 6;
   long item = blockIdx.x;
   const int split = (int)(item % p.splits); item /= p.splits;
   const int qtile = (int)(item % p.qtiles); item /= p.qtiles;
@@ -246,22 +251,47 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
     Raw ra, rb;
     int kb = kb0 + wave;
     if (kb < kb1) load_kv(kb, ra);
-    for (; kb < kb1; kb += 8) {
-      if (kb + 4 < kb1) load_kv(kb + 4, rb);
+    for (; kb < kb1; kb += 2 * NW) {
+      if (kb + NW < kb1) load_kv(kb + NW, rb);
       process(kb, ra);
-      if (kb + 4 < kb1) {
-        if (kb + 8 < kb1) load_kv(kb + 8, ra);
-        process(kb + 4, rb);
+      if (kb + NW < kb1) {
+        if (kb + 2 * NW < kb1) load_kv(kb + 2 * NW, ra);
+        process(kb + NW, rb);
       }
     }
   } else {
-    for (int kb = kb0 + wave; kb < kb1; kb += 4) {
+    for (int kb = kb0 + wave; kb < kb1; kb += NW) {
       Raw r;
       load_kv(kb, r);
       process(kb, r);
     }
   }
 
+  if constexpr (NW == 1) {
+    // ---- one wave owns the item: normalise and store from registers ----------------------------
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float lt = l[nt];
+      lt += __shfl_xor(lt, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+      if (col_qpos[nt] < 0) continue;
+      const float inv = lt > 0.f ? 1.f / lt : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const f32x4 acc = o[dt][nt];
+        if (p.splits == 1) {
+          u32x2 v = {pack_bf16(acc[0] * inv, acc[1] * inv), pack_bf16(acc[2] * inv, acc[3] * inv)};
+          *reinterpret_cast<u32x2*>(p.out + col_row[nt] * p.ldo + col_head[nt] * D + dt * 16 + quad * 4) = v;
+        } else {
+          const long rec = ((((long)b * p.Hkv + kvh) * p.qtiles + qtile) * p.splits + split) * NC + nt * 16 + l15;
+          float* r = p.partial + rec * (D + 4);
+          if (quad == 0 && dt == 0) { r[0] = m[nt]; r[1] = lt; }
+          *reinterpret_cast<f32x4*>(r + 4 + dt * 16 + quad * 4) = acc;
+        }
+      }
+    }
+    return;
+  }
   // ---- merge the 4 waves through LDS -----------------------------------------------------
   // layout: ml[w][nt][lane] = (m, l partial of this lane); oacc[w][dt][nt][lane] f32x4
   float* ml = reinterpret_cast<float*>(smem);                         // 4 * NT * 64 * 2 floats
@@ -312,6 +342,16 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) {
       }
     }
   }
+}
+
+template <int D, int NT, bool KV8>
+__global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) { paged_attn_body<D, NT, KV8, 4, true>(p); }
+
+// One wave per item, one block in flight per wave, registers capped so that 3 waves share a SIMD:
+// latency is hidden by the other waves instead of by a second set of K/V registers.
+template <int D, bool KV8>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void paged_attn_lean_kernel(AttnParams p) {
+  paged_attn_body<D, 1, KV8, 1, false>(p);
 }
 
 // Merge split-KV partials. One workgroup per (b, kv head, query tile); thread -> (column, 4 dims).
@@ -649,12 +689,25 @@ static void launch_prefill_attn(const AttnParams& p, hipStream_t stream) {
   else            hipLaunchKernelGGL((prefill_attn_kernel<D, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
 }
 
+// Work items from which one wave per item beats four (same box, Llama-3-8B heads, 150 cached
+// tokens: 1024 sequences 118 vs 130 us, 256: 30.6 vs 37.0, 128: 17.3 vs 21.3, 64: 13.1 vs 11.9; 64
+// sequences x 2000 tokens: 122 vs 94; e4m3 cache at 1024 sequences: 71 vs 101 us).
+// DLIA_ATTN_WAVE_ITEMS overrides the threshold for A/B runs (0: always four waves per item).
+static inline long wave_per_item_threshold() {
+  static const long v = [] { const char* e = getenv("DLIA_ATTN_WAVE_ITEMS"); return e ? atol(e) : 1024L; }();
+  return v;
+}
+
 template <int D, int NT>
 static void launch_attn(const AttnParams& p, hipStream_t stream) {
   const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
   constexpr size_t smem = 4 * NT * 64 * 2 * 4 + 4 * (D / 16) * NT * 64 * 16;
-  if (p.kv_scale) hipLaunchKernelGGL((paged_attn_kernel<D, NT, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
-  else            hipLaunchKernelGGL((paged_attn_kernel<D, NT, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
+  const long thr = wave_per_item_threshold();
+  if (NT == 1 && thr > 0 && nitems >= thr) {
+    if (p.kv_scale) hipLaunchKernelGGL((paged_attn_lean_kernel<D, true>), dim3((unsigned)nitems), dim3(64), 0, stream, p);
+    else            hipLaunchKernelGGL((paged_attn_lean_kernel<D, false>), dim3((unsigned)nitems), dim3(64), 0, stream, p);
+  } else if (p.kv_scale) hipLaunchKernelGGL((paged_attn_kernel<D, NT, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
+  else                   hipLaunchKernelGGL((paged_attn_kernel<D, NT, false>), dim3((unsigned)nitems), dim3(256), smem, stream, p);
   if (p.splits > 1)
     hipLaunchKernelGGL((attn_combine_kernel<D, NT>), dim3((unsigned)((long)p.B * p.Hkv * p.qtiles)), dim3(256), 0,
                        stream, p);

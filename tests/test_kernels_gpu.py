@@ -607,6 +607,26 @@ def test_attention_decode(K, geom):
     _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 1, 31, 32, 100, 257], q_lens=[1] * 6, splits=1)
 
 
+@pytest.mark.parametrize("kv8", [False, True])
+@pytest.mark.parametrize("geom", [(32, 8, 128), (32, 4, 64), (12, 12, 64), (64, 8, 128)])
+def test_attention_decode_one_wave_per_item(K, geom, kv8):
+    """From 1024 (sequence, kv head) items on, a decode step runs one wave per item (no cross-wave
+    merge): contexts of 0 tokens, one block exactly, one token into the next block, many blocks."""
+    Hq, Hkv, D = geom
+    B = 1024 // Hkv + 8
+    g = torch.Generator().manual_seed(Hq + D)
+    ctx = torch.randint(0, 200, (B,), generator=g).tolist()
+    ctx[:6] = [0, 1, 31, 32, 33, 64]
+    ctx[-1] = 700
+    _attn_case(K, Hq, Hkv, D, ctx_lens=ctx, q_lens=[1] * B, splits=1, kv8=kv8)
+
+
+def test_attention_decode_one_wave_per_item_with_split_kv(K):
+    ctx = [5, 700, 64, 333] * 10 + [1, 31]
+    _attn_case(K, 32, 8, 128, ctx_lens=ctx, q_lens=[1] * len(ctx), splits=4)          # 42 x 8 x 4 = 1344 items
+    _attn_case(K, 32, 8, 128, ctx_lens=ctx, q_lens=[1] * len(ctx), splits=4, kv8=True)
+
+
 @pytest.mark.parametrize("splits", [2, 4, 8])
 def test_attention_decode_splitkv(K, splits):
     _attn_case(K, 32, 8, 128, ctx_lens=[5, 700, 64, 333], q_lens=[1] * 4, splits=splits)
