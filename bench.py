@@ -9,12 +9,12 @@ random-init weights.
 
 One rank per GPU; rank = pipeline stage; hidden states hop stage to stage over RCCL send/recv,
 sampled token ids hop back from the last stage to stage 0. A "step" is one decode step of EVERY
-in-flight sequence: each of the 2N micro-batches (1024 sequences each) goes once through all N
+in-flight sequence: each of the 2N micro-batches (2048 sequences each) goes once through all N
 stages — embedding, every decoder layer against the paged KV cache, final norm, lm_head,
 temperature/top-k/top-p sampling, token feedback. Per-GPU work per step is constant in N (2N
 micro-batches x L/N layers), i.e. weak scaling. A stage rotates its micro-batches over 2 HIP
 streams, so the kernels of two micro-batches overlap on each GPU (measured on one MI355X:
-2 x 1024 rows 57.7k tok/s at 35 ms per token, 3 x 512 53.8k at 28 ms, 3 x 256 42.8k at 18 ms —
+2 x 2048 rows 67.1k tok/s at 61 ms per token, 2 x 1536 65.5k at 47 ms, 2 x 1024 61.5k at 33 ms —
 pick the latency point with --batch / --micro-batches / --decode-streams). Prefill of the synthetic prompts and W warm-up
 steps run first; then exactly K steps are timed between barrier + device-synchronize brackets,
 the MAX over ranks is taken, and rank 0 prints one JSON line.
@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--batch", type=int, default=0,
-                    help="sequences per micro-batch (default: 1024 for bf16 and fp8; 256 for fp8w, whose GEMM\n"
+                    help="sequences per micro-batch (default: 2048 for bf16 and fp8; 256 for fp8w, whose GEMM\n"
                          "streams at most 256 rows per pass)")
     ap.add_argument("--micro-batches", type=int, default=0,
                     help="in-flight micro-batches (default: 2 x gpus for bf16 and fp8, 3 x gpus for fp8w)")
@@ -239,11 +239,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    # operating point per dtype (measured on one MI355X): bf16 and fp8 2 x 1024 rows on 2 streams;
-    # the fp8-weights-only GEMM streams at most 256 rows per pass, so larger micro-batches would
-    # re-read its weights
+    # operating point per dtype (measured on one MI355X): bf16 and fp8 2 x 2048 rows on 2 streams
+    # (at 2048 rows the N = 4096 projections have 128 output tiles of 256 x 256 and need no split-K;
+    # same box, bf16: 2 x 1024 61.5 k tok/s at 33.3 ms per step, 2 x 1536 65.5 k at 46.9 ms, 2 x 2048
+    # 67.1 k at 61.1 ms; `--batch 1024` is the lower-latency point); the fp8-weights-only GEMM streams
+    # at most 256 rows per pass, so larger micro-batches would re-read its weights
     wide = a.dtype in ("bf16", "fp8")
-    a.batch = a.batch or (8 if a.cpu else (1024 if wide else 256))
+    a.batch = a.batch or (8 if a.cpu else (2048 if wide else 256))
     a.decode_streams = a.decode_streams or (2 if wide else 3)
     nmb = a.micro_batches or (2 if wide else 3) * max(1, world)
     max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32

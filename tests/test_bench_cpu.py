@@ -93,13 +93,14 @@ def test_micro_batch_shrinks_when_the_kv_cache_would_not_fit(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(total_memory=288 * 2 ** 30))
 
-    def fit(steps, world, model="llama-3-8b", dtype="bf16"):
-        a = types.SimpleNamespace(model=model, partition="balanced", batch=1024, prompt_len=128, steps=steps, warmup=4,
+    def fit(steps, world, model="llama-3-8b", dtype="bf16", batch=1024):
+        a = types.SimpleNamespace(model=model, partition="balanced", batch=batch, prompt_len=128, steps=steps, warmup=4,
                                   kv_dtype="bf16", dtype=dtype)
         max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
         return b._fit_batch(a, 2 * world, max_seq, world)
 
-    assert fit(32, 1) == 1024 and fit(32, 8) == 1024        # the driver's default fits at every N
+    assert fit(32, 1) == 1024 and fit(32, 8) == 1024
+    assert fit(32, 1, batch=2048) == 2048 and fit(32, 8, batch=2048) == 2048        # the driver's default fits at every N
     assert fit(1000, 1) == 512                              # 2 x 1024 x 1152 tokens x 128 KiB = 309 GB does not
     assert fit(1000, 8) < 1024
     # 70B on one GPU: 141 GB of bf16 weights leave room for 2 x 1024 x 192 tokens x 320 KiB, not for 2 x 1024 x 256;
