@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"])
     ap.add_argument("--layers", type=int, default=8, help="distinct caches cycled through, so no call finds its K/V in L2 / MALL")
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--heat", action="store_true",
+                    help="run a large GEMM between the timed calls and time each call with its own events: the clocks "
+                         "a decode step's GEMMs leave behind, not the idle-chip boost clock")
     ap.add_argument("--scatter", action="store_true", help="random block order instead of consecutive blocks per sequence")
     a = ap.parse_args()
     K = ops.load()
@@ -74,6 +77,21 @@ def main():
         for i in range(a.layers):
             fn(i)
         torch.cuda.synchronize()
+        if a.heat:
+            ha = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+            hb = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+            evs = []
+            for it in range(a.iters):
+                for _ in range(2):
+                    torch.matmul(ha, hb)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(it % a.layers)
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            ts = sorted(x.elapsed_time(y) * 1e3 for x, y in evs)
+            return ts[len(ts) // 2]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for it in range(a.iters):

@@ -25,6 +25,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--layers", type=int, default=0, help="truncate the model (profiling)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--readback", type=int, default=0, metavar="DEPTH",
+                    help="read every step's tokens back to the host the way the serving head does (side stream, pinned "
+                         "buffer) and keep at most DEPTH steps in flight, as the scheduler does")
+    ap.add_argument("--side-stream", action="store_true", help="run the steps on a non-default stream")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"])
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 KV cache with per-(token, head) scales")
     a = ap.parse_args()
@@ -54,9 +58,31 @@ def main():
     for _ in range(a.warmup):
         t = st.decode_step(b, x=t)
     torch.cuda.synchronize()
+    run_stream = torch.cuda.Stream() if a.side_stream else torch.cuda.current_stream()
+    res_stream = torch.cuda.Stream()
+    ring = [(torch.zeros(B, dtype=torch.int32, device="cuda"), torch.zeros(B, dtype=torch.int32).pin_memory()) for _ in range(6)]
+    inflight = []
     t1 = time.perf_counter()
-    for _ in range(a.steps):
-        t = st.decode_step(b, x=t)
+    with torch.cuda.stream(run_stream):
+        for i in range(a.steps):
+            if a.readback:
+                while len(inflight) >= a.readback:
+                    if inflight[0].query():
+                        inflight.pop(0)
+                    else:
+                        time.sleep(20e-6)
+                t = st.decode_step(b)              # single stage: the graph feeds its own tokens back
+                stg, host = ring[i % 6]
+                stg.copy_(t)
+                done, ev = torch.cuda.Event(), torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(res_stream):
+                    res_stream.wait_event(done)
+                    host.copy_(stg, non_blocking=True)
+                    ev.record()
+                inflight.append(ev)
+            else:
+                t = st.decode_step(b, x=t)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / a.steps
     wbytes = st.memory_report()["weights_gib"] * (1 << 30)

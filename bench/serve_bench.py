@@ -37,6 +37,8 @@ def main():
                     help="CLIENTS requests outstanding at any time, each completion submits the next (default: all at t = 0)")
     ap.add_argument("--admit-fill", type=float, default=None, help="EngineConfig.admit_fill_fraction")
     ap.add_argument("--admit-wait-ms", type=float, default=None, help="EngineConfig.admit_max_wait_ms")
+    ap.add_argument("--profile", action="store_true", help="cProfile the scheduler thread (in-process pipelines) and print the top of it to stderr")
+    ap.add_argument("--inflight", type=int, default=None, help="EngineConfig.max_inflight_steps")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="closed loop: spread the first CLIENTS arrivals over this long")
     a = ap.parse_args()
     cfg = EngineConfig(model=a.model, pp_size=a.pp_size, max_batch=a.batch, num_micro_batches=a.micro_batches,
@@ -45,8 +47,17 @@ def main():
                        transport="loopback" if a.cpu else "auto")
     if a.admit_fill is not None:
         cfg.admit_fill_fraction = a.admit_fill
+    if a.inflight is not None:
+        cfg.max_inflight_steps = a.inflight
     if a.admit_wait_ms is not None:
         cfg.admit_max_wait_ms = a.admit_wait_ms
+    prof = None
+    if a.profile:
+        import cProfile
+        from distributed_llm_inference_amd.runtime import engine as _eng
+        prof = cProfile.Profile()
+        inner = _eng.Engine._loop
+        _eng.Engine._loop = lambda self: prof.runcall(inner, self)
     pipe = make_pipeline(cfg)
     eng = pipe.engine
     g = torch.Generator().manual_seed(0)
@@ -91,6 +102,10 @@ def main():
     finally:
         snap = eng.snapshot()
         pipe.close()
+    if prof is not None:
+        import pstats
+        import sys as _sys
+        pstats.Stats(prof, stream=_sys.stderr).sort_stats("cumulative").print_stats(45)
     out_tokens = sum(len(r.output) for r in reqs)
     ttft = sorted((r.t_first - r.t_arrival) * 1e3 for r in reqs if r.t_first)
     tpot = sorted(((r.t_done - r.t_first) / max(1, len(r.output) - 1)) * 1e3 for r in reqs if r.t_first and r.t_done)

@@ -75,7 +75,12 @@ class LocalHead:
         self.on_gpu = runtime.on_gpu
         self._res_stream = torch.cuda.Stream(device=runtime.device) if self.on_gpu else None
         self._last_fb: Dict[int, Handle] = {}        # micro-batch -> arrival of its latest fed-back tokens
-        self._last_copy: Dict[int, object] = {}      # micro-batch -> event: its tokens have left the static buffer
+        # Token read-back: a step's ids are copied, on the step's own stream, into one of a few device
+        # staging rows, and from there to pinned host memory on a side stream. The next step of the
+        # micro-batch overwrites the static token buffer without waiting for that host copy (a
+        # cross-stream event round trip per step otherwise: ~0.3 ms per token at batch 1).
+        self._ring: Dict[tuple, list] = {}           # (micro-batch, n) -> [(staging, pinned host, event), ...]
+        self._ring_pos: Dict[tuple, int] = {}
 
     # ---- how a descriptor will run ----------------------------------------------------------
     def graph_decode(self, desc: StepBatch) -> bool:
@@ -97,32 +102,52 @@ class LocalHead:
     def control(self, desc: StepBatch):
         self.rt.execute(desc)
 
+    _RING = 6          # > max_inflight_steps + the results the scheduler has not read yet
+
+    def _slot(self, mb: int, n: int):
+        """Next (staging row, pinned host row) of micro-batch `mb` for `n` token ids; a slot comes
+        round again only after the scheduler has long consumed it, but its event is checked anyway."""
+        key = (mb, n)
+        ring = self._ring.get(key)
+        if ring is None:
+            ring = [[torch.zeros(max(n, 1), dtype=torch.int32, device=self.rt.device),
+                     torch.zeros(max(n, 1), dtype=torch.int32).pin_memory(), None] for _ in range(self._RING)]
+            self._ring[key], self._ring_pos[key] = ring, 0
+        i = self._ring_pos[key]
+        self._ring_pos[key] = (i + 1) % self._RING
+        slot = ring[i]
+        if slot[2] is not None:
+            slot[2].synchronize()
+        return slot
+
     def submit(self, d: StepBatch) -> StepResult:
         rt, mb = self.rt, d.micro_batch
         n_res = rt.result_count(d)
         fb_wait = self._last_fb.get(mb) if d.token_ids is None else None
         with rt.stream_scope(d):           # the stream this step runs on (one per decode micro-batch)
-            last_copy = self._last_copy.get(mb)
-            if self.on_gpu and last_copy is not None:
-                # the previous step's tokens must have left the static buffer before it is rewritten
-                torch.cuda.current_stream().wait_event(last_copy)
             tokens = rt.execute(d, fb_wait)
             if self.num_stages == 1:
                 if not self.on_gpu:
                     return StepResult(tokens=tokens)
-                host = torch.empty(n_res, dtype=torch.int32).pin_memory() if n_res else torch.empty(0, dtype=torch.int32)
+                if not n_res:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    return StepResult(event=ev, host=torch.empty(0, dtype=torch.int32))
+                slot = self._slot(mb, n_res)
+                stg, host = slot[0], slot[1]
+                stg.copy_(tokens)                          # same stream: ordered before the next step's overwrite
                 ev, done = torch.cuda.Event(), torch.cuda.Event()
                 done.record()
                 with torch.cuda.stream(self._res_stream):
                     self._res_stream.wait_event(done)
-                    if n_res:
-                        host.copy_(tokens, non_blocking=True)
+                    host.copy_(stg, non_blocking=True)
                     ev.record()
-                self._last_copy[mb] = ev
+                slot[2] = ev
                 return StepResult(event=ev, host=host)
             buf = rt.fb_buffer(mb, n_res)
             if self.on_gpu:
-                host = torch.empty(n_res, dtype=torch.int32).pin_memory()
+                slot = self._slot(mb, n_res)
+                host = slot[1]
                 ev, got = torch.cuda.Event(), torch.cuda.Event()
                 with torch.cuda.stream(self._res_stream):
                     h = self.links.fb_data.recv(buf) if n_res else None
@@ -132,6 +157,7 @@ class LocalHead:
                     if n_res:
                         host.copy_(buf, non_blocking=True)
                     ev.record()
+                slot[2] = ev
                 self._last_fb[mb] = _EventHandle(got)
                 return StepResult(event=ev, host=host)
             h = self.links.fb_data.recv(buf) if n_res else None
