@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--admit-fill", type=float, default=None, help="EngineConfig.admit_fill_fraction")
     ap.add_argument("--admit-wait-ms", type=float, default=None, help="EngineConfig.admit_max_wait_ms")
     ap.add_argument("--profile", action="store_true", help="cProfile the scheduler thread (in-process pipelines) and print the top of it to stderr")
+    ap.add_argument("--trace", default=None, help="EngineConfig.trace_path: Chrome trace of host and GPU spans")
+    ap.add_argument("--kv-blocks", type=int, default=None, help="EngineConfig.kv_blocks (default: sized from device memory)")
     ap.add_argument("--inflight", type=int, default=None, help="EngineConfig.max_inflight_steps")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="closed loop: spread the first CLIENTS arrivals over this long")
     a = ap.parse_args()
@@ -49,6 +51,10 @@ def main():
         cfg.admit_fill_fraction = a.admit_fill
     if a.inflight is not None:
         cfg.max_inflight_steps = a.inflight
+    if a.trace:
+        cfg.trace_path = a.trace
+    if a.kv_blocks is not None:
+        cfg.kv_blocks = a.kv_blocks
     if a.admit_wait_ms is not None:
         cfg.admit_max_wait_ms = a.admit_wait_ms
     prof = None

@@ -75,10 +75,11 @@ class LocalHead:
         self.on_gpu = runtime.on_gpu
         self._res_stream = torch.cuda.Stream(device=runtime.device) if self.on_gpu else None
         self._last_fb: Dict[int, Handle] = {}        # micro-batch -> arrival of its latest fed-back tokens
-        # Token read-back: a step's ids are copied, on the step's own stream, into one of a few device
-        # staging rows, and from there to pinned host memory on a side stream. The next step of the
-        # micro-batch overwrites the static token buffer without waiting for that host copy (a
-        # cross-stream event round trip per step otherwise: ~0.3 ms per token at batch 1).
+        # Token read-back. One stage: the ids go to pinned host memory on the step's own stream, right
+        # behind the graph (a side stream for the copy costs more than the copy: work arriving on a
+        # second hardware queue once per step slowed every kernel hand-over of a TinyLlama batch-1
+        # decode graph, 1.40 against 1.23 ms per token). Several stages: the feedback receive and the
+        # host copy run on a side stream, which has to wait for the last stage anyway.
         self._ring: Dict[tuple, list] = {}           # (micro-batch, n) -> [(staging, pinned host, event), ...]
         self._ring_pos: Dict[tuple, int] = {}
 
@@ -105,13 +106,12 @@ class LocalHead:
     _RING = 6          # > max_inflight_steps + the results the scheduler has not read yet
 
     def _slot(self, mb: int, n: int):
-        """Next (staging row, pinned host row) of micro-batch `mb` for `n` token ids; a slot comes
-        round again only after the scheduler has long consumed it, but its event is checked anyway."""
+        """Next pinned host row of micro-batch `mb` for `n` token ids; a slot comes round again only
+        after the scheduler has long consumed it, but its event is checked anyway."""
         key = (mb, n)
         ring = self._ring.get(key)
         if ring is None:
-            ring = [[torch.zeros(max(n, 1), dtype=torch.int32, device=self.rt.device),
-                     torch.zeros(max(n, 1), dtype=torch.int32).pin_memory(), None] for _ in range(self._RING)]
+            ring = [[None, torch.zeros(max(n, 1), dtype=torch.int32).pin_memory(), None] for _ in range(self._RING)]
             self._ring[key], self._ring_pos[key] = ring, 0
         i = self._ring_pos[key]
         self._ring_pos[key] = (i + 1) % self._RING
@@ -134,14 +134,10 @@ class LocalHead:
                     ev.record()
                     return StepResult(event=ev, host=torch.empty(0, dtype=torch.int32))
                 slot = self._slot(mb, n_res)
-                stg, host = slot[0], slot[1]
-                stg.copy_(tokens)                          # same stream: ordered before the next step's overwrite
-                ev, done = torch.cuda.Event(), torch.cuda.Event()
-                done.record()
-                with torch.cuda.stream(self._res_stream):
-                    self._res_stream.wait_event(done)
-                    host.copy_(stg, non_blocking=True)
-                    ev.record()
+                host = slot[1]
+                host.copy_(tokens, non_blocking=True)      # same stream: done before the next step overwrites `tokens`
+                ev = torch.cuda.Event()
+                ev.record()
                 slot[2] = ev
                 return StepResult(event=ev, host=host)
             buf = rt.fb_buffer(mb, n_res)
