@@ -198,6 +198,38 @@ def test_two_stage_processes_on_one_gpu_over_host_staged_gloo():
     assert got == ref
 
 
+@pytest.mark.parametrize("fault,hop_timeout", [("stage1:exit@3", 5), ("stage1:stall@3:3600", 2)],
+                         ids=["stage process dies", "stage hangs forever"])
+def test_gpu_stage_failure_is_answered_in_time_and_the_pipeline_is_replaced(fault, hop_timeout):
+    """Two HIP stage processes on the GPU (host-staged gloo); stage 1 dies, or stalls inside a call
+    that never returns, at its third step. The serving process holds no GPU context: `/generate`
+    answers {"status": "failed"} inside hop_timeout x stages (+ slack), `/workers` stops showing a
+    healthy pipeline, and the next request runs on freshly spawned stage processes (the old ones
+    are killed, not drained). Parity: orchestration.py:118-122,220-228,306-329."""
+    import time
+    from distributed_llm_inference_amd.parallel.launcher import make_pipeline
+    from distributed_llm_inference_amd.serving.orchestrator import EngineBackend
+    from distributed_llm_inference_amd.utils.procs import pid_alive
+    pipe = make_pipeline(cfg(pp_size=2, partition="even", num_micro_batches=3, transport="gloo", fault_inject=fault,
+                             hop_timeout_s=hop_timeout, auto_restart=True))
+    b = EngineBackend(pipe)
+    try:
+        pipe.wait_ready(timeout=240)
+        old_pids = [p.pid for p in pipe.procs]
+        t0 = time.time()
+        first = b.generate("Hello", 20, 0.0)
+        took = time.time() - t0
+        assert first["status"] == "failed" and first["error"].startswith("Error: "), first
+        assert took < hop_timeout * 2 + 15, took
+        assert b.workers()["worker_2"] != "online" or "stall" in fault
+        second = b.generate("Hello", 6, 0.0)                  # spawns fresh stages, loads, runs
+        assert second["status"] == "success" and second["tokens_generated"] == 6, second
+        assert b.restarts == 1 and b.workers() == {"worker_1": "online", "worker_2": "online"}
+        assert not any(pid_alive(p) for p in old_pids)
+    finally:
+        b.close()
+
+
 def test_fp8_kv_cache_through_the_engine():
     """kv_dtype fp8 on the full serving path (continuous batching, hipGraph decode, 2 stages): every
     request completes, and greedy tokens mostly agree with the bf16-cache run (quantisation noise may
