@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--model", default="llama-3-8b")
     ap.add_argument("--m", type=int, nargs="+", default=[512, 2048, 8192])
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--no-split", action="store_true", help="no workspace: the bf16 kernel cannot split K inside the launch")
+    ap.add_argument("--no-split", action="store_true", help="no workspace: the 256 x 256 kernel cannot split K inside the launch")
     ap.add_argument("--a8w8", action="store_true", help="the fp8 x fp8 kernel (e4m3 operands, MX MFMA) instead of bf16")
     a = ap.parse_args()
     K = ops.load()
@@ -31,7 +31,7 @@ def main():
             n_out = N // 2 if epi == 4 else N
             out = torch.empty(M, n_out, device="cuda", dtype=torch.bfloat16)
             res = torch.randn(M, n_out, device="cuda").to(torch.bfloat16) if epi == 2 else None
-            need = 0 if a.a8w8 or a.no_split else int(K.gemm_ws_floats(M, N, Kd))
+            need = 0 if a.no_split else int(K.gemm_ws_floats(M, N, Kd))
             ws = torch.zeros(need + 4096, device="cuda") if need else None
             if a.a8w8:
                 wq, wsc = packing.pack_weight_a8w8(torch.randn(N, Kd, device="cuda") * 0.02)
@@ -41,7 +41,7 @@ def main():
 
             def run():
                 if a.a8w8:
-                    K.gemm_a8w8(out, xq, xs, wq, wsc, None, res, None, N, epi, 1, 0)
+                    K.gemm_a8w8(out, xq, xs, wq, wsc, None, res, ws, N, epi, 1, 0)
                 else:
                     K.gemm(out, x, wp, None, res, ws, N, epi, 1, 0)
             for _ in range(2):

@@ -186,7 +186,7 @@ class GpuStage:
         # front, or the slabs of the large-M kernel's in-launch split-K; the last 4096 words are that
         # kernel's arrival counters and must stay zero between launches (nobody else writes there)
         ws_floats = self._ws_floats
-        if self.wmode == "bf16":
+        if self.wmode in ("bf16", "fp8"):        # (the e4m3 kernel splits at most as far as the bf16 one)
             for m_ in {rows, min(rows, 512), min(rows, 1024)}:
                 if m_ > DECODE_ROWS:
                     ws_floats = max([ws_floats] + [int(self.K.gemm_ws_floats(m_, n_, k_)) for n_, k_ in self._gemm_shapes])
@@ -343,9 +343,9 @@ class GpuStage:
 
         if T > DECODE_ROWS:
             # compute-bound regime (large decode micro-batches, prefill chunks): tiled MFMA GEMMs with
-            # fused bias / residual / activation epilogues; the bf16 kernel splits K inside the launch
-            # on shapes with fewer tiles than CUs and needs the workspace for that
-            lws = wk.ws if self.wmode == "bf16" else None
+            # fused bias / residual / activation epilogues; the 256 x 256 kernel (bf16 and e4m3) splits
+            # K inside the launch on shapes with fewer tiles than CUs and needs the workspace for that
+            lws = wk.ws if self.wmode in ("bf16", "fp8") else None
             for li, p in enumerate(self.layers):
                 x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
                 self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, 1, 0)

@@ -340,7 +340,6 @@ void quant_rows(Tensor q, Tensor scale, const Tensor& x) {
 }
 
 // fp8 x fp8 GEMM: xq uint8 [M,K] + xscale[M], wp from pack_weight_a8w8 + wscale per packed row.
-// More than 256 rows run as 256-row slices (weights re-streamed per slice).
 void gemm_a8w8(Tensor out, const Tensor& xq, const Tensor& xscale, const Tensor& wp, const Tensor& wscale,
                OptTensor bias, OptTensor residual, OptTensor workspace, int64_t N, int64_t epi, int64_t splitk,
                int64_t ntw) {
@@ -400,9 +399,17 @@ void gemm_a8w8(Tensor out, const Tensor& xq, const Tensor& xscale, const Tensor&
                    ws, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, sk, (int)ntw, stream);
   } else {
     DLIA_CHECK(epi != 6, "partial output is a decode-regime (M <= 256) feature");
-    // more than 256 rows: one launch, the kernel walks 256-row blocks
-    dlia_gemm_a8w8(out.data_ptr(), xq.data_ptr(), xscale.data_ptr<float>(), wp.data_ptr(), wscale.data_ptr<float>(), bp, rp,
-                   nullptr, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, 1, 2, stream);
+    // more than 256 rows: one launch of the 256 x 256 ping-pong kernel (or, DLIA_GEMM_LARGE=stream, the loader-wave
+    // kernel walking 256-row blocks). A workspace lets thin shapes split K inside the launch, as for bf16: slabs in
+    // front, its last 4096 words are arrival counters (zero when first handed over, left zero by every launch).
+    float* wsp = nullptr; int64_t wsn = 0;
+    if (workspace.has_value()) {
+      check_f32(*workspace, "workspace");
+      DLIA_CHECK(workspace->is_contiguous(), "gemm workspace must be contiguous");
+      wsp = workspace->data_ptr<float>(); wsn = workspace->numel();
+    }
+    dlia_gemm_a8w8_large(out.data_ptr(), xq.data_ptr(), xscale.data_ptr<float>(), wp.data_ptr(), wscale.data_ptr<float>(), bp, rp,
+                         wsp, wsn, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
   }
 }
 

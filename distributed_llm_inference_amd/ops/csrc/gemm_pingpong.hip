@@ -74,7 +74,16 @@ __device__ __forceinline__ void pp_barrier() {
 }
 
 template <int V> using ic = std::integral_constant<int, V>;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
+// F8: both operands are OCP e4m3 bytes (x rows of p.ldx BYTES with per-row scales p.xscale, W from
+// pack_weight_a8w8 with per-column scales p.wscale). Every byte count, LDS address, DMA piece and
+// wait count is the same as for bf16: a 128-byte x row piece then holds 128 K-elements, the two
+// 1 KiB weight blocks of a (n-tile, K-tile) are the two halves of one 32-byte-per-lane fragment, and a
+// cluster is 8 x v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) instead of 16 x 16x16x32 —
+// the same 512 matrix-pipe cycles, twice the arithmetic. Lane (r, q) of an x fragment holds
+// k = 32 q .. 32 q + 31 of row r: the 16-byte slots 2 q and 2 q + 1 of its row.
+template <bool F8>
 __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   const int cb = (rest / mblocks) * 8 + (blockIdx.x & 7);
   if (cb >= nb) return;                          // grid padded to 8 column blocks; whole workgroup, before any barrier
   const int mblk = rest % mblocks, mrow0 = mblk * 256;
-  const int tiles_total = p.K >> 6, KT = tiles_total * 2;
+  const int tiles_total = p.K >> (F8 ? 7 : 6), KT = tiles_total * 2;   // K-tile = 128 bytes of an x row
   const int per = (tiles_total + p.splitk - 1) / p.splitk;
   const int c0 = ks * per;
   const int n = min(tiles_total, c0 + per) - c0;   // K-tiles of this split (>= 1 by the launcher)
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   // ---- DMA sources: per half-tile this wave moves pieces 2 wave and 2 wave + 1 -----------------
   // x piece: 8 rows x 128 B (rows past M re-read the last row; never stored). weight piece: one
   // (n-tile, k-step) block; a column half past the packed width re-reads n-tile `wave` (never stored).
-  const long ldxb = p.ldx * 2;
+  const long ldxb = F8 ? p.ldx : p.ldx * 2;      // row stride in bytes
   const char* asrc[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        af[i][kk] = *reinterpret_cast<const u32x4*>(base + i * 2048 + (((kk * 4 + quad) ^ sw) << 4));
+        af[i][kk] = *reinterpret_cast<const u32x4*>(base + i * 2048 + (((F8 ? 2 * quad + kk : kk * 4 + quad) ^ sw) << 4));
   };
   auto read_b = [&](int par, auto half_c, u32x4 (&bf)[2][2]) {
     constexpr int h = decltype(half_c)::value;
@@ -166,12 +175,24 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   };
   auto cluster = [&](f32x4 (&c)[4][2], const u32x4 (&bf)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    if constexpr (F8) {
+      auto join = [](const u32x4& lo, const u32x4& hi) {
+        return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      };
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) c[i][j] = mfma16(bf[j][kk], af[i][kk], c[i][j]);
+        for (int j = 0; j < 2; ++j)
+          c[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(join(bf[j][0], bf[j][1]), join(af[i][0], af[i][1]), c[i][j],
+                                                                     0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) c[i][j] = mfma16(bf[j][kk], af[i][kk], c[i][j]);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -267,6 +288,31 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
       __hip_atomic_store(stored, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if constexpr (F8) {
+    // dequantise: per output column (weight row) and per row (token); sums over K splits are linear
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int tile = min(cb * 16 + hn * 8 + wc * 2 + j, p.ntiles - 1);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.wscale + tile * 16 + quad * 4);
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[hm][hn][i][j] *= sc;
+      }
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mrow0 + hm * 128 + wr * 64 + i * 16 + l15;
+        const float xs = p.xscale[m < p.M ? m : p.M - 1];
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[hm][hn][i][j] *= xs;
+      }
+  }
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -288,15 +334,16 @@ extern "C" int dlia_gemm_large_choice(int which) {
 // K splits for a shape: as many as keep the launch within `target` workgroups (default 128: half the
 // CUs — the serving path runs two micro-batches on two streams, and a thin launch shares the chip
 // with the other stream's kernels), each split at least 8 K-tiles long, at most 8 splits.
-extern "C" int dlia_gemm_pingpong_splitk(int M, int N, int K) {
+static int pp_splitk(int M, int N, int ktiles) {
   static const int target = [] { const char* e = getenv("DLIA_GEMM_PP_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
-  const int tiles = ((M + 255) / 256) * ((packed_ntiles(N) + 15) / 16), ktiles = K / 64;
+  const int tiles = ((M + 255) / 256) * ((packed_ntiles(N) + 15) / 16);
   if (tiles > kPPCounters / 2) return 1;
   int s = target / tiles;
   if (s > 8) s = 8;
   while (s > 1 && ktiles / s < 8) --s;
   return s < 1 ? 1 : s;
 }
+extern "C" int dlia_gemm_pingpong_splitk(int M, int N, int K) { return pp_splitk(M, N, K / 64); }
 // Workspace the split needs: slabs [tiles][S][256 x 256]; the arrival counters are the LAST
 // kPPCounters words of whatever workspace the caller hands over (so that workspaces shared with
 // other users of their front part keep them intact).
@@ -309,16 +356,18 @@ extern "C" long dlia_gemm_pingpong_ws_floats(int M, int N, int K) {
 // bf16, M > 256 (any M is correct; below that the weight-streaming kernels are faster), K a
 // multiple of 64; `p` fully set up by the caller. p->splitk > 1 needs p->partial = slabs for
 // [tiles][splitk - 1] and p->counters = two zero words per tile (the kernel leaves them zero).
-extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
+template <bool F8>
+static void launch_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
   static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pingpong_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pingpong_kernel<F8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kPPLds);
     return true;
   }();
   (void)once;
   const int nb = (p->ntiles + 15) / 16, nb8 = (nb + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
-  hipLaunchKernelGGL(gemm_pingpong_kernel, dim3(nb8 * mblocks * p->splitk), dim3(kPPThreads), kPPLds, stream, *p);
+  hipLaunchKernelGGL(gemm_pingpong_kernel<F8>, dim3(nb8 * mblocks * p->splitk), dim3(kPPThreads), kPPLds, stream, *p);
 }
+extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream) { launch_pingpong<false>(p, stream); }
 
 // out[M,N] = epi(x[M,K] @ Wp^T) for bf16 weights and more than 256 rows (epilogues 0..5 as
 // dlia_gemm_skinny). `workspace` (may be null) of `ws_floats` floats: lets thin shapes split K; its
@@ -342,4 +391,28 @@ extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const 
     p.counters = reinterpret_cast<int*>(workspace + ws_floats - kPPCounters);
   }
   dlia_gemm_pingpong(&p, stream);
+}
+
+// The same for e4m3 x e4m3 (dlia_gemm_a8w8's contract: xq bytes [M, K] with row stride ldx BYTES,
+// xscale[M], wp from pack_weight_a8w8, wscale per packed row), more than 256 rows, K a multiple of 128.
+extern "C" void dlia_gemm_a8w8_large(void* out, const void* xq, const float* xscale, const void* wp, const float* wscale,
+                                     const void* bias, const void* residual, float* workspace, long ws_floats, int M,
+                                     int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return;
+  GemmParams p;
+  p.x = (const bf16*)xq; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = wscale; p.xscale = xscale; p.out = out; p.ldo = ldo;
+  p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;
+  p.residual = (epi == 2 || epi == 3) ? (const bf16*)residual : nullptr;
+  p.ldr = ldr; p.partial = workspace; p.M = M; p.N = N; p.K = K;
+  p.ntiles = packed_ntiles(N);
+  p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
+  p.out_f32 = out_f32; p.partial_only = 0; p.splitk = 1; p.group_n = 1; p.counters = nullptr;
+  if (dlia_gemm_large_choice(-1) != 0) { p.partial = nullptr; dlia_gemm_rows_f8(&p, stream); return; }
+  const int s = pp_splitk(M, N, K / 128);
+  const long tiles = (long)((M + 255) / 256) * ((p.ntiles + 15) / 16);
+  if (workspace && s > 1 && ws_floats >= tiles * (s - 1) * kPPSlab + kPPCounters) {
+    p.splitk = s;
+    p.counters = reinterpret_cast<int*>(workspace + ws_floats - kPPCounters);
+  }
+  launch_pingpong<true>(&p, stream);
 }

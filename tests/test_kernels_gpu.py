@@ -418,6 +418,60 @@ def test_gemm_pingpong_split_k_inside_the_launch(K, shape):
         K.large_gemm_kernel(prev)
 
 
+@pytest.mark.parametrize("shape", [(1024, 4096, 4096, 2), (512, 6144, 4096, 0), (1024, 4096, 14336, 2), (512, 4096, 4096, 3),
+                                   (700, 1152, 4096, 4), (300, 384, 2048, 5)])
+def test_gemm_a8w8_pingpong_split_k_inside_the_launch(K, shape):
+    """The e4m3 x e4m3 instantiation of the 256 x 256 kernel on shapes that split K inside the launch
+    (half as many K-tiles as bf16 for the same K): against the fp32 product of the dequantised
+    operands, repeatedly on one workspace, counters back at zero, slabs actually used."""
+    M, N, Kd, epi = shape
+    prev = K.large_gemm_kernel(0)
+    try:
+        torch.manual_seed(2)
+        x = bf(torch.randn(M, Kd, device=DEV) * (1 + torch.arange(M, device=DEV).view(-1, 1) % 5))
+        xq = torch.zeros(M, Kd, device=DEV, dtype=torch.uint8)
+        xs = torch.zeros(M, device=DEV)
+        K.quant_rows(xq, xs, x)
+        x_ref = packing.dequantize_fp8(xq, xs)
+        if epi == 4:
+            wg, wu = (torch.randn(N // 2, Kd, device=DEV) / math.sqrt(Kd) for _ in range(2))
+            wp, sc = packing.pack_weight_a8w8(packing.interleave_gate_up(wg, wu))
+            w_ref = torch.cat([packing.dequantize_fp8(*packing.quantize_fp8(wg)), packing.dequantize_fp8(*packing.quantize_fp8(wu))], 0)
+            n_out = N // 2
+        else:
+            w = torch.randn(N, Kd, device=DEV) / math.sqrt(Kd) * (1 + torch.arange(N, device=DEV).view(-1, 1) % 7)
+            wp, sc = packing.pack_weight_a8w8(w)
+            w_ref, n_out = packing.dequantize_fp8(*packing.quantize_fp8(w)), N
+        bias, res = bf(torch.randn(n_out, device=DEV)), bf(torch.randn(M, n_out, device=DEV))
+        want = ref.gemm(x_ref, w_ref, bias, res, epi)
+        ws = torch.zeros(int(K.gemm_ws_floats(M, N, Kd)) + 4096, device=DEV, dtype=torch.float32)
+        for it in range(3):
+            out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.bfloat16)
+            K.gemm_a8w8(out, xq, xs, wp, sc, bias, res, ws, N, epi, 1, 0)
+            assert_close(out, want, 3e-2, 2e-2, f"a8w8 split-K gemm {shape} launch {it}")
+            assert int(ws[-4096:].view(torch.int32).abs().sum()) == 0, "arrival counters not reset"
+        assert float(ws[:-4096].abs().sum()) > 0, "no slab was written: the shape did not split"
+        out32 = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.float32)
+        K.gemm_a8w8(out32, xq, xs, wp, sc, bias, res, None, N, epi, 1, 0)          # and unsplit, fp32 out
+        assert_close(out32, want, 2e-3, 2e-3, f"a8w8 gemm {shape} without workspace")
+    finally:
+        K.large_gemm_kernel(prev)
+
+
+@pytest.mark.parametrize("which", [0, 2], ids=["pingpong", "stream"])
+@pytest.mark.parametrize("shape", [(257, 128, 128), (300, 512, 384), (768, 640, 896), (2048, 256, 1024), (513, 1152, 512)])
+def test_gemm_a8w8_large_kernels_agree_on_edge_shapes(K, which, shape):
+    """One K-tile, an odd number of K-tiles, a column block with one half only (N = 128, 640, 1152),
+    row blocks ending mid-tile: both large-M e4m3 kernels against the dequantised product."""
+    M, N, Kd = shape
+    prev = K.large_gemm_kernel(which)
+    try:
+        _gemm_a8w8_case(K, M, N, Kd, 3, 1)
+        _gemm_a8w8_case(K, M, N, Kd, 0, 1, out_f32=True)
+    finally:
+        K.large_gemm_kernel(prev)
+
+
 def test_gemm_pingpong_exact_on_integer_data_with_asymmetric_operands(K):
     """Small integers are exact in bf16 and fp32: every output element must equal the integer product
     exactly, with an x that is not symmetric and weights that differ per column (a swapped row/column
