@@ -320,7 +320,7 @@ def main():
                        "micro_batch_size": cfg.max_batch, "layer_ranges": plans,
                        "weak_scaling_bound_from_partition": bound,
                        "sampling": "temperature 0.7, top-k 50, top-p 0.9", "hipgraph_decode": bool(cfg.use_graphs and not a.cpu), "decode_streams": cfg.decode_streams,
-                       "backend": rt.ex.backend, "transport": cfg.resolved_transport(), "kv_cache": "fp32" if a.cpu else cfg.kv_dtype}}), flush=True)
+                       "backend": rt.ex.backend, "transport": getattr(rt.links, "transport", None) or cfg.resolved_transport(), "kv_cache": "fp32" if a.cpu else cfg.kv_dtype}}), flush=True)
     if world > 1:
         import torch.distributed as dist
         try:

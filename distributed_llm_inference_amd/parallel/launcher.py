@@ -195,6 +195,47 @@ def init_distributed(rank: int, world: int, backend: str, master_port: int, devi
     return dist
 
 
+def rccl_links_or_fallback(rank: int, world: int, job: str, device: str, slot: int,
+                           warmup_timeout_s: float = 120.0):
+    """The stage's links over the native RCCL hops — or, when any rank fails to bring them up, over
+    the next transport that every rank can: `torch.distributed` NCCL point-to-point groups, then gloo
+    with activations staged through pinned host memory. The ranks agree after every attempt (a MIN
+    over the gloo default group), so they always end up on the same transport; a failed attempt's
+    hops are aborted and closed first. `links.transport` names what is in use. A pipeline that comes
+    up slower beats one that does not come up (the reference's answer to an unreachable worker is an
+    error string per request: orchestration.py:118-122)."""
+    import torch.distributed as dist
+    from ..utils.tracing import get_logger
+    from .transport import make_dist_links, make_rccl_links
+    attempts = [
+        ("rccl", lambda j: make_rccl_links(rank, world, j, device, ctrl_slot_bytes=slot, warmup_timeout_s=warmup_timeout_s)),
+        ("rccl-torch", lambda j: make_dist_links(rank, world, "nccl", j, host_staged=False, ctrl_slot_bytes=slot)),
+        ("gloo", lambda j: make_dist_links(rank, world, "gloo", j, host_staged=True, ctrl_slot_bytes=slot)),
+    ]
+    log = get_logger()
+    last = None
+    for i, (name, make) in enumerate(attempts):
+        links, err = None, None
+        try:
+            links = make(job if i == 0 else f"{job}_t{i}")       # fresh ring names per attempt
+        except BaseException as e:                                # noqa: BLE001 - reported below, agreed on by all ranks
+            err = e
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            links.transport = name
+            if i > 0:
+                log.warning("stage %d: pipeline links are on the %s transport (fallback %d)", rank, name, i)
+            return links
+        if err is not None:
+            log.warning("stage %d: %s transport did not come up: %s: %s", rank, name, type(err).__name__, err)
+            last = err
+        if links is not None:
+            links.abort()
+            links.close()
+    raise RuntimeError(f"no stage-to-stage transport could be brought up on every rank (last error: {last})")
+
+
 def _group_backend(transport: str) -> str:
     """torch.distributed backend of the default group for a transport: the native RCCL hops and
     gloo both use a gloo group; "rccl-torch" moves activations through ProcessGroupNCCL itself."""
@@ -235,8 +276,7 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
         if world == 1:
             links = make_loopback_links(1)[0]
         elif transport == "rccl" and dev_kind == "cuda":
-            from .transport import make_rccl_links
-            links = make_rccl_links(rank, world, job, device, ctrl_slot_bytes=slot)
+            links = rccl_links_or_fallback(rank, world, job, device, slot)
         else:
             links = make_dist_links(rank, world, backend, job, host_staged=(dev_kind == "cuda" and backend == "gloo"),
                                     ctrl_slot_bytes=slot)

@@ -282,6 +282,7 @@ class PipelineLinks:
         self.fb_data: Optional[Edge] = None        # tokens: last stage -> stage 0 (both ends hold it)
         self.prev_ctrl: Optional[Control] = None   # descriptors from stage-1
         self.next_ctrl: Optional[Control] = None   # descriptors to stage+1
+        self.transport: Optional[str] = None       # set when the transport was chosen at run time (fallback chain)
 
     @property
     def is_first(self) -> bool:

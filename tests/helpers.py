@@ -98,3 +98,43 @@ def divergences_are_near_ties(ref_stage, prompts, got, want, rel=0.05, abs_tol=0
         assert gap <= tol, (f"sequence {k} diverges at token {n}: engine chose {g[n]}, reference {w[n]}, "
                             f"reference logit gap {gap:.4f} > tolerance {tol:.4f}")
     return diverged
+
+
+def fallback_rank_main(rank: int, world: int, port: int, tmpdir: str):
+    """One rank of the transport-fallback test: the first transport fails on rank 1 only, the second
+    on both, the third works; every rank must end up on the third and a failed attempt's links must
+    have been aborted and closed. Writes what it saw to tmpdir/rank<r>.json."""
+    import json
+    import os
+    import torch.distributed as dist
+    from distributed_llm_inference_amd.parallel import launcher, transport
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = {"closed": 0, "aborted": 0, "jobs": []}
+
+    class FakeLinks(transport.PipelineLinks):
+        def abort(self):
+            seen["aborted"] += 1
+
+        def close(self):
+            seen["closed"] += 1
+
+    def native(r, w, job, device, ctrl_slot_bytes=0, warmup_timeout_s=0):
+        seen["jobs"].append(job)
+        if r == 1:
+            raise RuntimeError("ncclCommInitRank: unhandled system error (test)")
+        return FakeLinks(r, w)
+
+    def torch_groups(r, w, backend, job, host_staged=False, ctrl_slot_bytes=0):
+        seen["jobs"].append(job)
+        if backend == "nccl":
+            raise RuntimeError("Duplicate GPU detected (test)")
+        return FakeLinks(r, w)
+
+    transport.make_rccl_links, transport.make_dist_links = native, torch_groups
+    links = launcher.rccl_links_or_fallback(rank, world, "job", "cpu", 4096)
+    seen["transport"] = links.transport
+    with open(os.path.join(tmpdir, f"rank{rank}.json"), "w") as f:
+        json.dump(seen, f)
+    dist.barrier()
+    dist.destroy_process_group()

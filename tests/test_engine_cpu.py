@@ -3,6 +3,8 @@ batches, chunked prefill, continuous batching, EOS / token-cap semantics, and a 
 multi-process 2-stage pipeline over gloo with shared-memory control rings."""
 import threading
 
+import os
+
 import pytest
 import torch
 
@@ -307,3 +309,19 @@ def test_descriptor_ring_slots_are_sized_from_the_configuration():
                       token_ids=[1] * (2 * B), table_slots=list(range(B)), table_blocks=[[7]] * (B - 1) + [[7] * 1024],
                       grow_slots=list(range(B)), grow_pos=[1] * B, grow_blocks=[3] * B)
     assert len(worst.to_bytes()) <= ctrl_slot_bytes(c)
+
+
+def test_ranks_agree_on_a_fallback_transport_when_one_of_them_cannot_bring_the_first_up(tmp_path):
+    """Native RCCL hops -> torch.distributed NCCL groups -> host-staged gloo: an attempt that fails on
+    ANY rank is abandoned by ALL ranks (its links aborted and closed where they came up), so a
+    pipeline never ends up with two ends of a hop on different transports."""
+    import json
+    import torch.multiprocessing as mp
+    from helpers import fallback_rank_main
+    port = 29000 + (os.getpid() % 1000)
+    mp.spawn(fallback_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    assert [g["transport"] for g in got] == ["gloo", "gloo"]
+    assert got[0]["aborted"] == 1 and got[0]["closed"] == 1          # rank 0's native links came up and were dropped
+    assert got[1]["aborted"] == 0 and got[1]["closed"] == 0
+    assert got[0]["jobs"] == ["job", "job_t1", "job_t2"]             # fresh ring names per attempt
