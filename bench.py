@@ -106,6 +106,7 @@ class Driver:
         self.step_id = 0
         self.lat_events = [[] for _ in range(self.nmb)]
         self.blocks_per_seq = (cfg.max_seq_len + 31) // 32
+        self._probe = StepBatch(slots=list(range(self.B)), q_lens=[1] * self.B)    # "a whole micro-batch decoding"
 
     def _desc(self, mb, q_lens, ctx_lens, sample, token_ids, replay=False, tables=False):
         B = self.B
@@ -143,6 +144,10 @@ class Driver:
                 span = max(1, min(1000, self.rt.ex.spec.vocab_size - 20))
                 d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, [(7 * (mb * B + i)) % span + 10 for i in range(B)])
                 fbw = None
+            elif self.rt._graph_decode(self._probe):
+                self.step_id += 1
+                d = StepBatch.replay_of(self.step_id, mb, B, B)          # header-only descriptor: the stages replay their graphs
+                fbw = self.fb[mb]
             else:
                 d = self._desc(mb, [1] * B, [ctx] * B, [1] * B, None, replay=True)
                 fbw = self.fb[mb]

@@ -28,7 +28,8 @@ KIND_PING = 4        # liveness probe, forwarded down the pipe and acknowledged 
 KIND_BARRIER = 5     # drain all outstanding work, then meet every other stage at a barrier
 
 _MAGIC = 0x444C4942  # "DLIB"
-_HEAD = "<IiiiiiiIi"    # magic, kind, step id, micro-batch, B, tokens (-1: none), table ints, replay, growth entries
+_HEAD = "<IiiiiiiIii"   # magic, kind, step id, micro-batch, B, tokens (-1: none), table ints, flags, growth entries, live rows
+_F_REPLAY, _F_COMPACT = 1, 2
 
 
 @dataclass
@@ -60,25 +61,48 @@ class StepBatch:
     # decode fast path: all q_lens == 1 and the composition is unchanged since the previous
     # step of this micro-batch, so stages may replay their captured graph as is
     replay: bool = False
+    # Compact replay descriptor: the per-sequence arrays are left out altogether (a stage replaying
+    # its captured graph reads none of them; at 2048 rows they are 80 KB and a millisecond of
+    # packing per stage and step). `rows` = sequences of the micro-batch, `live` = those that decode.
+    rows: int = -1
+    live: int = -1
+
+    @property
+    def compact(self) -> bool:
+        return self.rows >= 0
 
     @property
     def num_seqs(self) -> int:
-        return len(self.slots)
+        return self.rows if self.rows >= 0 else len(self.slots)
 
     @property
     def num_tokens(self) -> int:
-        return int(sum(self.q_lens))
+        return self.live if self.rows >= 0 else int(sum(self.q_lens))
 
     @property
     def is_decode(self) -> bool:
         """Single-token step (rows with q_len 0 are padding of a fixed-shape micro-batch)."""
+        if self.rows >= 0:
+            return self.live > 0
         return bool(self.q_lens) and all(q in (0, 1) for q in self.q_lens) and any(q == 1 for q in self.q_lens)
 
     @property
     def num_samples(self) -> int:
-        return int(sum(self.sample))
+        return self.live if self.rows >= 0 else int(sum(self.sample))
+
+    @staticmethod
+    def replay_of(step_id: int, micro_batch: int, rows: int, live: int) -> "StepBatch":
+        """The descriptor of "the same micro-batch once more" (only valid for stages that run
+        fixed-shape decode steps over static buffers; growth entries may be added)."""
+        return StepBatch(step_id=step_id, micro_batch=micro_batch, replay=True, rows=rows, live=live)
 
     def validate(self):
+        if self.compact:
+            if not self.replay or self.token_ids is not None or self.table_slots or self.slots:
+                raise ValueError("a compact descriptor is a bare replay")
+            if not (len(self.grow_slots) == len(self.grow_pos) == len(self.grow_blocks)):
+                raise ValueError("grow_slots / grow_pos / grow_blocks mismatch")
+            return
         B = self.num_seqs
         for name in ("q_lens", "ctx_lens", "sample", "temperature", "top_k", "top_p", "seeds", "sample_steps"):
             if len(getattr(self, name)) != B:
@@ -93,6 +117,11 @@ class StepBatch:
 
     # ---- wire format ------------------------------------------------------------------
     def to_bytes(self) -> bytes:
+        if self.compact:
+            ng = len(self.grow_slots)
+            head = struct.pack(_HEAD, _MAGIC, self.kind, self.step_id, self.micro_batch, self.rows, -1, 0,
+                               _F_REPLAY | _F_COMPACT, ng, self.live)
+            return head + np.asarray(self.grow_slots + self.grow_pos + self.grow_blocks, dtype="<i4").tobytes()
         B = self.num_seqs
         ntok = -1 if self.token_ids is None else len(self.token_ids)
         tb_flat: List[int] = []
@@ -100,7 +129,7 @@ class StepBatch:
             tb_flat += [s, len(blocks)] + list(blocks)
         ng = len(self.grow_slots)
         head = struct.pack(_HEAD, _MAGIC, self.kind, self.step_id, self.micro_batch, B, ntok,
-                           len(tb_flat), 1 if self.replay else 0, ng)
+                           len(tb_flat), _F_REPLAY if self.replay else 0, ng, -1)
         ints = np.asarray(self.slots + self.q_lens + self.ctx_lens + self.sample + self.top_k +
                           self.sample_steps + tb_flat + self.grow_slots + self.grow_pos + self.grow_blocks +
                           (self.token_ids or []), dtype="<i4")
@@ -111,9 +140,14 @@ class StepBatch:
     @staticmethod
     def from_bytes(buf: bytes) -> "StepBatch":
         hs = struct.calcsize(_HEAD)
-        magic, kind, step_id, mb, B, ntok, ntb, replay, ng = struct.unpack_from(_HEAD, buf, 0)
+        magic, kind, step_id, mb, B, ntok, ntb, flags, ng, live = struct.unpack_from(_HEAD, buf, 0)
         if magic != _MAGIC:
             raise ValueError("bad step descriptor magic")
+        replay = flags & _F_REPLAY
+        if flags & _F_COMPACT:
+            g = np.frombuffer(buf, dtype="<i4", count=3 * ng, offset=hs).tolist()
+            return StepBatch(kind=kind, step_id=step_id, micro_batch=mb, replay=True, rows=B, live=live,
+                             grow_slots=g[:ng], grow_pos=g[ng:2 * ng], grow_blocks=g[2 * ng:])
         n_int = 6 * B + ntb + 3 * ng + max(ntok, 0)
         ints = np.frombuffer(buf, dtype="<i4", count=n_int, offset=hs).tolist()
         off = hs + 4 * n_int

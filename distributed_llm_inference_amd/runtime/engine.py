@@ -557,11 +557,28 @@ class Engine:
     def _submit_decode(self, mb: _MicroBatch, replay: bool) -> bool:
         """Issues one decode step of `mb`. False (nothing issued) when a row needs a KV block the
         pool does not have."""
-        d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, replay=replay,
-                      token_ids=None if replay else [])
+        compact = replay and self._static_decode       # stages replay a captured graph: no per-row fields needed
+        if compact:
+            d = StepBatch.replay_of(self._next_step_id(), mb.idx, len(mb.rows), 0)
+        else:
+            d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, replay=replay,
+                          token_ids=None if replay else [])
         if not self._grow(mb, d):
             return False
         rows: List[Optional[Request]] = []
+        if compact:
+            n_live = 0
+            for r in mb.rows:
+                live = r is not None and r.state == "running"
+                if live:
+                    r.issued_ctx += 1
+                    r.issued_samples += 1
+                    n_live += 1
+                rows.append(r if live else None)
+            d.live = n_live
+            self.stats["decode_steps"] += 1
+            self._submit(mb, d, rows)
+            return True
         for i, r in enumerate(mb.rows):
             live = r is not None and r.state == "running"
             # fixed shape: every row of the micro-batch is present, dead/empty ones as padding

@@ -292,6 +292,27 @@ def test_step_descriptor_wire_roundtrip():
         StepBatch(slots=[1], q_lens=[1, 2]).validate()
 
 
+def test_compact_replay_descriptor_is_a_header_and_growth_entries():
+    """A replay step of a stage that runs its captured graph carries no per-sequence arrays: 40 bytes
+    + growth entries instead of 40 bytes per row, whatever the micro-batch size."""
+    d = StepBatch.replay_of(step_id=11, micro_batch=2, rows=2048, live=2000)
+    d.grow_slots, d.grow_pos, d.grow_blocks = [5, 9], [4, 4], [700, 701]
+    d.validate()
+    b = d.to_bytes()
+    assert len(b) == 40 + 6 * 4
+    e = StepBatch.from_bytes(b)
+    assert e.compact and e.replay and e.step_id == 11 and e.micro_batch == 2
+    assert e.num_seqs == 2048 and e.num_tokens == 2000 and e.num_samples == 2000 and e.is_decode
+    assert (e.grow_slots, e.grow_pos, e.grow_blocks) == ([5, 9], [4, 4], [700, 701])
+    assert StepBatch.from_bytes(e.to_bytes()).to_bytes() == b           # forwarded down the pipeline unchanged
+    with pytest.raises(ValueError):
+        StepBatch(replay=False, rows=8, live=8).validate()
+    full = StepBatch(slots=list(range(2048)), q_lens=[1] * 2048, ctx_lens=[9] * 2048, sample=[1] * 2048,
+                     temperature=[0.7] * 2048, top_k=[50] * 2048, top_p=[0.9] * 2048, seeds=[1] * 2048,
+                     sample_steps=[0] * 2048, replay=True)
+    assert len(full.to_bytes()) > 80000 and not StepBatch.from_bytes(full.to_bytes()).compact
+
+
 # ---- native runtime ---------------------------------------------------------------------------
 def test_block_allocator_all_or_nothing():
     from distributed_llm_inference_amd.runtime.kv_cache import BlockAllocator, blocks_for
