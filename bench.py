@@ -57,6 +57,7 @@ def parse():
                     help="in-flight micro-batches (default: 2 x gpus for bf16 and fp8, 3 x gpus for fp8w)")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")
+    ap.add_argument("--whole-layers", action="store_true", help="balanced partition over whole layers only (A/B)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--decode-streams", type=int, default=0,
                     help="HIP streams the decode micro-batches of a stage alternate over")
@@ -219,10 +220,10 @@ def _fit_batch(a, nmb: int, max_seq: int, world: int) -> int:
     for more than the device has: halve the micro-batch until the largest stage's share fits in 85 %
     of what its weights leave, and say so (the size used is reported in the JSON line's config)."""
     from distributed_llm_inference_amd.parallel.launcher import plans_for, resolve_spec
-    cfg = EngineConfig(model=a.model, pp_size=world, partition=a.partition)
+    cfg = EngineConfig(model=a.model, pp_size=world, partition=a.partition, split_layers=not getattr(a, "whole_layers", False))
     spec = resolve_spec(cfg)
     plans = plans_for(cfg, spec)
-    layers = max(p.layer_end - p.layer_start for p in plans)
+    layers = max(len(p.attn_layers) for p in plans)           # one KV cache per attention block of a stage
     wbytes = 1 if a.dtype in ("fp8", "fp8w") else 2
     weights = max((p.layer_end - p.layer_start) * spec.layer_param_count()
                   + (spec.embed_param_count() if p.has_embed else 0) + (spec.head_param_count() if p.has_head else 0)
@@ -256,7 +257,7 @@ def main():
     max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
     if not a.cpu:
         a.batch = _fit_batch(a, nmb, max_seq, max(1, world))
-    cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb,
+    cfg = EngineConfig(model=a.model, pp_size=world, max_batch=a.batch, num_micro_batches=nmb, split_layers=not a.whole_layers,
                        max_seq_len=max_seq, prefill_chunk=max(2048, a.prompt_len), partition=a.partition,
                        use_graphs=not a.no_graph, device="cpu" if a.cpu else "auto",
                        backend="torch" if a.cpu else "auto", seed=0, dtype=a.dtype, decode_streams=a.decode_streams,

@@ -26,6 +26,7 @@ class EngineConfig:
     # ---- pipeline ----------------------------------------------------------------------
     pp_size: int = 1                       # number of pipeline stages (= processes = GPUs)
     partition: str = "balanced"            # "balanced" | "even" | "explicit"
+    split_layers: bool = True              # balanced: a stage boundary may fall between a layer's attention and MLP blocks
     layer_ranges: Optional[List[Tuple[int, int]]] = None
     backend: str = "auto"                  # stage executor: "hip" | "torch" | "auto"
     device: str = "auto"                   # "cuda" | "cpu" | "auto"

@@ -120,16 +120,24 @@ class GpuStage:
         self.layers: List[Dict[str, torch.Tensor]] = []
         for i in range(len(weights.layers)):
             l = weights.layers[i]
-            p: Dict[str, torch.Tensor] = {"ln1_w": g(l["ln1_w"]), "ln2_w": g(l["ln2_w"])}
-            self._pack(p, "w_qkv", g(l["w_qkv"]))
-            self._pack(p, "w_o", g(l["w_o"]))
-            self._pack(p, "w_down", g(l["w_down"]))
-            if spec.is_llama:
-                self._pack(p, "w_gu", packing.interleave_gate_up(g(l["w_gate"]), g(l["w_up"])))
-            else:
-                self._pack(p, "w_fc", g(l["w_fc"]))
+            # a stage boundary may fall between a layer's attention and MLP blocks: the first / last
+            # layer of a stage then holds the tensors of one block only
+            p: Dict[str, torch.Tensor] = {}
+            if "w_qkv" in l:
+                p["ln1_w"] = g(l["ln1_w"])
+                self._pack(p, "w_qkv", g(l["w_qkv"]))
+                self._pack(p, "w_o", g(l["w_o"]))
+            if "w_down" in l:
+                p["ln2_w"] = g(l["ln2_w"])
+                self._pack(p, "w_down", g(l["w_down"]))
+                if spec.is_llama:
+                    self._pack(p, "w_gu", packing.interleave_gate_up(g(l["w_gate"]), g(l["w_up"])))
+                else:
+                    self._pack(p, "w_fc", g(l["w_fc"]))
+            if not spec.is_llama:
                 for k in ("ln1_b", "ln2_b", "b_qkv", "b_o", "b_fc", "b_down"):
-                    p[k] = g(l[k])
+                    if k in l:
+                        p[k] = g(l[k])
             self.layers.append(p)
             weights.layers[i] = {}                 # drop the logical copy as we go (peak memory)
         self.vocab_pad = packing.padded_n(V)
@@ -227,6 +235,7 @@ class GpuStage:
 
     def _kvwrite(self, li, qkv, part, S, pbias, tok_pos, tok_seq):
         s = self.spec
+        li -= 1 if self.plan.skip_attn_first else 0        # caches are numbered over this stage's attention blocks
         if self.kv8:
             self.K.rope_kvwrite8(qkv, part, S, pbias, self.kv[li], self.kv_scale[li], self.cos, self.sin, tok_pos, tok_seq,
                                  self.block_table, s.num_heads, s.num_kv_heads, s.head_dim, s.is_llama)
@@ -236,6 +245,7 @@ class GpuStage:
 
     def _attention(self, li, attn, qkv, q_start, ctx, slots, partial, max_q, splits):
         s = self.spec
+        li -= 1 if self.plan.skip_attn_first else 0
         if self.kv8:
             self.K.paged_attention8(attn, qkv, self.kv[li], self.kv_scale[li], q_start, ctx, self.block_table, slots, partial,
                                     max_q, s.num_heads, s.num_kv_heads, s.head_dim, self.scale, splits)
@@ -249,7 +259,7 @@ class GpuStage:
         fp32 scale per token, kv head and K|V)."""
         s = self.spec
         per_elem = (s.head_dim + 4) if self.kv8 else s.head_dim * 2
-        return max(1, self.plan.num_layers) * s.num_kv_heads * 2 * BLOCK * per_elem
+        return max(1, len(self.plan.attn_layers)) * s.num_kv_heads * 2 * BLOCK * per_elem
 
     def _decode_state_bytes(self) -> int:
         """What one decode micro-batch will allocate on first use (activations, split-K partials,
@@ -275,7 +285,7 @@ class GpuStage:
         return int(max(16, min(blocks, self.max_slots * self.max_blocks)))
 
     def allocate_kv(self, num_blocks: int):
-        s, L, dev = self.spec, self.plan.num_layers, self.device
+        s, L, dev = self.spec, len(self.plan.attn_layers), self.device      # one cache per attention block of this stage
         self.num_blocks = int(num_blocks)
         # zero-filled: masked-out (never written) slots must hold finite values, P=0 times NaN is NaN
         self.kv = torch.zeros(max(L, 1), self.num_blocks, s.num_kv_heads, 2, BLOCK * s.head_dim,
@@ -347,11 +357,14 @@ class GpuStage:
             # K inside the launch on shapes with fewer tiles than CUs and needs the workspace for that
             lws = wk.ws if self.wmode in ("bf16", "fp8") else None
             for li, p in enumerate(self.layers):
-                x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
-                self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, 1, 0)
-                self._kvwrite(li, qkv, None, 1, None, tok_pos, tok_seq)
-                self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
-                self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 2 if llama else 3, 1, 0)
+                if "w_qkv" in p:            # attention block (absent from a first layer whose attention ran upstream)
+                    x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
+                    self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, 1, 0)
+                    self._kvwrite(li, qkv, None, 1, None, tok_pos, tok_seq)
+                    self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
+                    self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 2 if llama else 3, 1, 0)
+                if "w_down" not in p:       # MLP block runs on the next stage
+                    continue
                 x2 = norm(None, 1, None, p["ln2_w"], p.get("ln2_b"))
                 if llama:
                     self._gemm(wk, act, x2, p, "w_gu", None, None, lws, 2 * I, 4, 1, 0)
@@ -368,15 +381,20 @@ class GpuStage:
         nd, sd = self._cfg(T, H, I, 6)
         pend = None
         for li, p in enumerate(self.layers):
-            if pend is None:
-                x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
-            else:
-                x1 = norm(ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"))
-            self._gemm(wk, qkv, x1, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
-            self._kvwrite(li, qkv, ws, sq, p.get("b_qkv"), tok_pos, tok_seq)
-            self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
-            self._gemm(wk, h, attn, p, "w_o", None, None, ws, H, 6, so, no)
-            x2 = norm(ws, so, p.get("b_o"), p["ln2_w"], p.get("ln2_b"))
+            if "w_qkv" in p:
+                if pend is None:
+                    x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
+                else:
+                    x1 = norm(ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"))
+                self._gemm(wk, qkv, x1, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
+                self._kvwrite(li, qkv, ws, sq, p.get("b_qkv"), tok_pos, tok_seq)
+                self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
+                self._gemm(wk, h, attn, p, "w_o", None, None, ws, H, 6, so, no)
+                pend = (so, p.get("b_o"))
+            if "w_down" not in p:           # MLP block runs on the next stage: the O partials are folded by the caller
+                continue
+            x2 = norm(None, 1, None, p["ln2_w"], p.get("ln2_b")) if pend is None else \
+                norm(ws, pend[0], pend[1], p["ln2_w"], p.get("ln2_b"))
             if llama:
                 self._gemm(wk, act, x2, p, "w_gu", None, None, ws, 2 * I, 4, 0, 0)
             else:

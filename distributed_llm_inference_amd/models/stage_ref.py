@@ -91,6 +91,7 @@ class RefStage:
         Hq, Hkv, D = spec.num_heads, spec.num_kv_heads, spec.head_dim
         scale = D ** -0.5
         for li, l in enumerate(self.w.layers):
+          if "w_qkv" in l:                 # (a stage boundary may fall between a layer's attention and MLP blocks)
             xn = self._norm(h, l["ln1_w"], l.get("ln1_b"))
             qkv = R.gemm(xn, l["w_qkv"], l.get("b_qkv"), None, 1 if "b_qkv" in l else 0).to(self.dtype)
             q = qkv[:, :Hq * D].reshape(T, Hq, D)
@@ -115,6 +116,7 @@ class RefStage:
                 attn[t0:t0 + qlen] = o.reshape(qlen, Hq * D).to(self.dtype)
                 t0 += qlen
             h = R.gemm(attn, l["w_o"], l.get("b_o"), h, 3 if "b_o" in l else 2).to(self.dtype)
+          if "w_down" in l:
             xn = self._norm(h, l["ln2_w"], l.get("ln2_b"))
             if spec.is_llama:
                 act = R.gemm(xn, torch.cat([l["w_gate"], l["w_up"]], 0), None, None, 4).to(self.dtype)

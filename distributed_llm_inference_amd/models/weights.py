@@ -117,23 +117,29 @@ def random_stage_weights(spec: ModelSpec, plan: StagePlan, seed: int = 0, device
     for i in plan.layers:
         p = f"layers.{i}."
         l: Dict[str, torch.Tensor] = {}
-        l["ln1_w"] = ones(H) + _randn(p + "ln1_w", (H,), seed, device, dtype, std=0.05)
-        l["w_qkv"] = _randn(p + "w_qkv", (spec.qkv_size, H), seed, device, dtype)
-        l["w_o"] = _randn(p + "w_o", (H, spec.q_size), seed, device, dtype)
-        l["ln2_w"] = ones(H) + _randn(p + "ln2_w", (H,), seed, device, dtype, std=0.05)
+        attn, mlp = plan.has_attn(i), plan.has_mlp(i)       # a stage boundary may fall between a layer's two blocks
+        if attn:
+            l["ln1_w"] = ones(H) + _randn(p + "ln1_w", (H,), seed, device, dtype, std=0.05)
+            l["w_qkv"] = _randn(p + "w_qkv", (spec.qkv_size, H), seed, device, dtype)
+            l["w_o"] = _randn(p + "w_o", (H, spec.q_size), seed, device, dtype)
+        if mlp:
+            l["ln2_w"] = ones(H) + _randn(p + "ln2_w", (H,), seed, device, dtype, std=0.05)
         if spec.is_llama:
-            l["w_gate"] = _randn(p + "w_gate", (I, H), seed, device, dtype)
-            l["w_up"] = _randn(p + "w_up", (I, H), seed, device, dtype)
-            l["w_down"] = _randn(p + "w_down", (H, I), seed, device, dtype)
+            if mlp:
+                l["w_gate"] = _randn(p + "w_gate", (I, H), seed, device, dtype)
+                l["w_up"] = _randn(p + "w_up", (I, H), seed, device, dtype)
+                l["w_down"] = _randn(p + "w_down", (H, I), seed, device, dtype)
         else:
-            l["ln1_b"] = _randn(p + "ln1_b", (H,), seed, device, dtype)
-            l["ln2_b"] = _randn(p + "ln2_b", (H,), seed, device, dtype)
-            l["b_qkv"] = _randn(p + "b_qkv", (spec.qkv_size,), seed, device, dtype)
-            l["b_o"] = _randn(p + "b_o", (H,), seed, device, dtype)
-            l["w_fc"] = _randn(p + "w_fc", (I, H), seed, device, dtype)
-            l["b_fc"] = _randn(p + "b_fc", (I,), seed, device, dtype)
-            l["w_down"] = _randn(p + "w_down", (H, I), seed, device, dtype)
-            l["b_down"] = _randn(p + "b_down", (H,), seed, device, dtype)
+            if attn:
+                l["ln1_b"] = _randn(p + "ln1_b", (H,), seed, device, dtype)
+                l["b_qkv"] = _randn(p + "b_qkv", (spec.qkv_size,), seed, device, dtype)
+                l["b_o"] = _randn(p + "b_o", (H,), seed, device, dtype)
+            if mlp:
+                l["ln2_b"] = _randn(p + "ln2_b", (H,), seed, device, dtype)
+                l["w_fc"] = _randn(p + "w_fc", (I, H), seed, device, dtype)
+                l["b_fc"] = _randn(p + "b_fc", (I,), seed, device, dtype)
+                l["w_down"] = _randn(p + "w_down", (H, I), seed, device, dtype)
+                l["b_down"] = _randn(p + "b_down", (H,), seed, device, dtype)
         w.layers.append(l)
     if plan.has_head:
         w.final_norm_w = ones(H) + _randn("final_norm_w", (H,), seed, device, dtype, std=0.05)
@@ -155,9 +161,10 @@ def stage_tensor_names(spec: ModelSpec, plan: StagePlan, available=None) -> List
             names.append("model.embed_tokens.weight")
         for i in plan.layers:
             p = f"model.layers.{i}."
-            names += [p + "input_layernorm.weight", p + "post_attention_layernorm.weight"]
-            names += [p + f"self_attn.{x}_proj.weight" for x in "qkvo"]
-            names += [p + f"mlp.{x}_proj.weight" for x in ("gate", "up", "down")]
+            if plan.has_attn(i):
+                names += [p + "input_layernorm.weight"] + [p + f"self_attn.{x}_proj.weight" for x in "qkvo"]
+            if plan.has_mlp(i):
+                names += [p + "post_attention_layernorm.weight"] + [p + f"mlp.{x}_proj.weight" for x in ("gate", "up", "down")]
         if plan.has_head:
             names.append("model.norm.weight")
             if not spec.tie_embeddings:
@@ -169,7 +176,8 @@ def stage_tensor_names(spec: ModelSpec, plan: StagePlan, available=None) -> List
             names.append("wpe.weight")
         for i in plan.layers:
             p = f"h.{i}."
-            for m in ("ln_1", "ln_2", "attn.c_attn", "attn.c_proj", "mlp.c_fc", "mlp.c_proj"):
+            for m in (("ln_1", "attn.c_attn", "attn.c_proj") if plan.has_attn(i) else ()) + \
+                     (("ln_2", "mlp.c_fc", "mlp.c_proj") if plan.has_mlp(i) else ()):
                 names += [p + m + ".weight", p + m + ".bias"]
         if plan.has_head:
             names += ["ln_f.weight", "ln_f.bias"]
@@ -193,17 +201,20 @@ def load_stage_weights(model_dir: str, spec: ModelSpec, plan: StagePlan, device=
             w.embed = get("model.embed_tokens.weight")
         for i in plan.layers:
             p = f"model.layers.{i}."
-            l = {
-                "ln1_w": get(p + "input_layernorm.weight"),
-                "w_qkv": torch.cat([get(p + "self_attn.q_proj.weight"),
-                                    get(p + "self_attn.k_proj.weight"),
-                                    get(p + "self_attn.v_proj.weight")], dim=0),
-                "w_o": get(p + "self_attn.o_proj.weight"),
-                "ln2_w": get(p + "post_attention_layernorm.weight"),
-                "w_gate": get(p + "mlp.gate_proj.weight"),
-                "w_up": get(p + "mlp.up_proj.weight"),
-                "w_down": get(p + "mlp.down_proj.weight"),
-            }
+            l = {}
+            if plan.has_attn(i):
+                l.update({
+                    "ln1_w": get(p + "input_layernorm.weight"),
+                    "w_qkv": torch.cat([get(p + "self_attn.q_proj.weight"),
+                                        get(p + "self_attn.k_proj.weight"),
+                                        get(p + "self_attn.v_proj.weight")], dim=0),
+                    "w_o": get(p + "self_attn.o_proj.weight")})
+            if plan.has_mlp(i):
+                l.update({
+                    "ln2_w": get(p + "post_attention_layernorm.weight"),
+                    "w_gate": get(p + "mlp.gate_proj.weight"),
+                    "w_up": get(p + "mlp.up_proj.weight"),
+                    "w_down": get(p + "mlp.down_proj.weight")})
             w.layers.append(l)
         if plan.has_head:
             w.final_norm_w = get("model.norm.weight")
@@ -217,14 +228,17 @@ def load_stage_weights(model_dir: str, spec: ModelSpec, plan: StagePlan, device=
         for i in plan.layers:
             p = f"{pre}h.{i}."
             # Conv1D stores [in, out]; the engine wants [out, in]
-            l = {
-                "ln1_w": get(p + "ln_1.weight"), "ln1_b": get(p + "ln_1.bias"),
-                "w_qkv": get(p + "attn.c_attn.weight").t().contiguous(), "b_qkv": get(p + "attn.c_attn.bias"),
-                "w_o": get(p + "attn.c_proj.weight").t().contiguous(), "b_o": get(p + "attn.c_proj.bias"),
-                "ln2_w": get(p + "ln_2.weight"), "ln2_b": get(p + "ln_2.bias"),
-                "w_fc": get(p + "mlp.c_fc.weight").t().contiguous(), "b_fc": get(p + "mlp.c_fc.bias"),
-                "w_down": get(p + "mlp.c_proj.weight").t().contiguous(), "b_down": get(p + "mlp.c_proj.bias"),
-            }
+            l = {}
+            if plan.has_attn(i):
+                l.update({
+                    "ln1_w": get(p + "ln_1.weight"), "ln1_b": get(p + "ln_1.bias"),
+                    "w_qkv": get(p + "attn.c_attn.weight").t().contiguous(), "b_qkv": get(p + "attn.c_attn.bias"),
+                    "w_o": get(p + "attn.c_proj.weight").t().contiguous(), "b_o": get(p + "attn.c_proj.bias")})
+            if plan.has_mlp(i):
+                l.update({
+                    "ln2_w": get(p + "ln_2.weight"), "ln2_b": get(p + "ln_2.bias"),
+                    "w_fc": get(p + "mlp.c_fc.weight").t().contiguous(), "b_fc": get(p + "mlp.c_fc.bias"),
+                    "w_down": get(p + "mlp.c_proj.weight").t().contiguous(), "b_down": get(p + "mlp.c_proj.bias")})
             w.layers.append(l)
         if plan.has_head:
             w.final_norm_w = get(pre + "ln_f.weight")
@@ -246,16 +260,18 @@ def export_hf_state_dict(parts: List[StageWeights]) -> Dict[str, torch.Tensor]:
                 sd["model.embed_tokens.weight"] = w.embed
             for i, l in zip(w.plan.layers, w.layers):
                 p = f"model.layers.{i}."
-                q, k, v = torch.split(l["w_qkv"], [spec.q_size, spec.kv_size, spec.kv_size], dim=0)
-                sd[p + "input_layernorm.weight"] = l["ln1_w"]
-                sd[p + "self_attn.q_proj.weight"] = q
-                sd[p + "self_attn.k_proj.weight"] = k
-                sd[p + "self_attn.v_proj.weight"] = v
-                sd[p + "self_attn.o_proj.weight"] = l["w_o"]
-                sd[p + "post_attention_layernorm.weight"] = l["ln2_w"]
-                sd[p + "mlp.gate_proj.weight"] = l["w_gate"]
-                sd[p + "mlp.up_proj.weight"] = l["w_up"]
-                sd[p + "mlp.down_proj.weight"] = l["w_down"]
+                if "w_qkv" in l:
+                    q, k, v = torch.split(l["w_qkv"], [spec.q_size, spec.kv_size, spec.kv_size], dim=0)
+                    sd[p + "input_layernorm.weight"] = l["ln1_w"]
+                    sd[p + "self_attn.q_proj.weight"] = q
+                    sd[p + "self_attn.k_proj.weight"] = k
+                    sd[p + "self_attn.v_proj.weight"] = v
+                    sd[p + "self_attn.o_proj.weight"] = l["w_o"]
+                if "w_down" in l:
+                    sd[p + "post_attention_layernorm.weight"] = l["ln2_w"]
+                    sd[p + "mlp.gate_proj.weight"] = l["w_gate"]
+                    sd[p + "mlp.up_proj.weight"] = l["w_up"]
+                    sd[p + "mlp.down_proj.weight"] = l["w_down"]
             if w.plan.has_head:
                 sd["model.norm.weight"] = w.final_norm_w
                 if not spec.tie_embeddings:
@@ -267,12 +283,14 @@ def export_hf_state_dict(parts: List[StageWeights]) -> Dict[str, torch.Tensor]:
                 sd[pre + "wpe.weight"] = w.pos_embed
             for i, l in zip(w.plan.layers, w.layers):
                 p = f"{pre}h.{i}."
-                sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = l["ln1_w"], l["ln1_b"]
-                sd[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"] = l["w_qkv"].t(), l["b_qkv"]
-                sd[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"] = l["w_o"].t(), l["b_o"]
-                sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = l["ln2_w"], l["ln2_b"]
-                sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = l["w_fc"].t(), l["b_fc"]
-                sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = l["w_down"].t(), l["b_down"]
+                if "w_qkv" in l:
+                    sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = l["ln1_w"], l["ln1_b"]
+                    sd[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"] = l["w_qkv"].t(), l["b_qkv"]
+                    sd[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"] = l["w_o"].t(), l["b_o"]
+                if "w_down" in l:
+                    sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = l["ln2_w"], l["ln2_b"]
+                    sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = l["w_fc"].t(), l["b_fc"]
+                    sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = l["w_down"].t(), l["b_down"]
             if w.plan.has_head:
                 sd[pre + "ln_f.weight"], sd[pre + "ln_f.bias"] = w.final_norm_w, w.final_norm_b
     return {k: v.detach().clone().contiguous() for k, v in sd.items()}

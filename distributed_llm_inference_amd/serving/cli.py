@@ -29,6 +29,8 @@ def _add_engine_args(ap):
     ap.add_argument("--pp-size", type=int)
     ap.add_argument("--partition", choices=["balanced", "even", "explicit"])
     ap.add_argument("--layer-ranges", help='explicit ranges, e.g. "0-11,11-22"')
+    ap.add_argument("--whole-layers", action="store_true",
+                    help="balanced partition over whole layers only (default: boundaries may fall between a layer's attention and MLP blocks)")
     ap.add_argument("--backend", choices=["auto", "hip", "torch"])
     ap.add_argument("--device", choices=["auto", "cuda", "cpu"])
     ap.add_argument("--transport", choices=["auto", "rccl", "rccl-torch", "gloo", "loopback", "http"],
@@ -75,6 +77,8 @@ def config_from_args(a) -> EngineConfig:
         base["auto_restart"] = True
     if getattr(a, "isolate", False):
         base["isolate"] = True
+    if getattr(a, "whole_layers", False):
+        base["split_layers"] = False
     if getattr(a, "pp_size", None) is not None and getattr(a, "num_micro_batches", None) is None:
         base["num_micro_batches"] = 0
     return EngineConfig.from_dict(base)

@@ -325,3 +325,24 @@ def test_ranks_agree_on_a_fallback_transport_when_one_of_them_cannot_bring_the_f
     assert got[0]["aborted"] == 1 and got[0]["closed"] == 1          # rank 0's native links came up and were dropped
     assert got[1]["aborted"] == 0 and got[1]["closed"] == 0
     assert got[0]["jobs"] == ["job", "job_t1", "job_t2"]             # fresh ring names per attempt
+
+
+@pytest.mark.parametrize("model", ["tiny-llama-test", "tiny-gpt2-test"])
+def test_stage_boundaries_inside_layers_keep_the_tokens(model):
+    """3, 5 and 7 stages over a 4-layer model: boundaries fall between attention and MLP blocks
+    (3 stages: 0-1.5 | 1.5-3 | 3-4). Same greedy tokens as one stage."""
+    from distributed_llm_inference_amd.parallel.launcher import plans_for, resolve_spec
+    ps = prompts(5, seed=17)
+    one = LocalPipeline(cfg(model=model))
+    try:
+        want = run(one, ps, greedy(10))
+    finally:
+        one.close()
+    for pp in (3, 5, 7):
+        c = cfg(model=model, pp_size=pp, num_micro_batches=pp + 1)
+        assert any(p.skip_attn_first for p in plans_for(c, resolve_spec(c)))
+        pipe = LocalPipeline(c)
+        try:
+            assert run(pipe, ps, greedy(10)) == want, f"pp={pp}"
+        finally:
+            pipe.close()

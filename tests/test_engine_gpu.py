@@ -43,12 +43,12 @@ def run(c, ps, params, timeout=120, executors=None):
     return outs, snap
 
 
-def test_pp1_pp2_pp4_identical_greedy_tokens_on_gpu():
+def test_pp1_to_pp5_identical_greedy_tokens_on_gpu():
     """Splitting the layers over stages only moves bf16 rows between buffers: tokens are identical."""
     ps = prompts(13)
     ref, _ = run(cfg(), ps, greedy(24))
     assert all(len(o) == 24 for o in ref)
-    for pp in (2, 4):
+    for pp in (2, 3, 4, 5):         # 3 and 5 stages: boundaries between attention and MLP blocks (0-1.5 | 1.5-3 | 3-4)
         got, snap = run(cfg(pp_size=pp, num_micro_batches=pp + 1), ps, greedy(24))
         assert got == ref, f"pp={pp}"
         assert snap["fatal"] is None

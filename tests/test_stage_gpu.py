@@ -162,6 +162,50 @@ def test_graph_decode_split_stage_hidden_handoff():
         assert torch.equal(tf, t2), f"step {i}"
 
 
+@pytest.mark.parametrize("family,wdtype", [("llama", "bf16"), ("gpt2", "bf16"), ("llama", "fp8")])
+def test_stage_boundaries_between_attention_and_mlp_blocks(family, wdtype):
+    """Three GpuStages whose boundaries fall INSIDE layers (0-1.5 | 1.5-3 with the head: attention of
+    layer 1 on the first stage, its MLP on the second) == one full-model stage: a 300-token prefill
+    chunk (compute-bound GEMM regime), a short chunk and graph decode steps (split-K partials folded
+    across the boundary), and each stage holds only the tensors and KV caches of its blocks."""
+    import dataclasses
+    from distributed_llm_inference_amd.models.partition import plans_from_blocks
+    from distributed_llm_inference_amd.models.stage_gpu import GpuStage
+    spec = dataclasses.replace(gpu_spec(family), max_position=512)
+    full_plan = make_plans(spec, 1)[0]
+    plans = plans_from_blocks(3, [(0, 3), (3, 4), (4, 6)])          # blocks: attn0 mlp0 attn1 | mlp1 | attn2 mlp2
+    assert [p.describe() for p in plans] == ["0-1.5", "1.5-2", "2-3"]
+    mk = lambda plan: GpuStage(spec, plan, random_stage_weights(spec, plan, seed=4, dtype=torch.bfloat16),
+                               max_slots=4, max_seq_len=512, num_blocks=48, max_tokens=320, max_batch=4, weight_dtype=wdtype)
+    full, st = mk(full_plan), [mk(pl) for pl in plans]
+    assert [len(x.layers) for x in st] == [2, 1, 1] and "w_down" not in st[0].layers[1] and "w_qkv" not in st[1].layers[0]
+    assert [x.kv.shape[0] for x in st] == [2, 1, 1]                 # (a stage without attention keeps a 1-layer dummy)
+
+    def chain(fn, b, x):
+        for stg in st:
+            x = fn(stg, b, x)
+        return x
+
+    torch.manual_seed(5)
+    ids = torch.randint(3, spec.vocab_size, (300 + 20,), dtype=torch.int32)
+    b = step([1, 2], [300, 20], [0, 0], tables={1: list(range(3, 14)), 2: [20, 21]})
+    lf = full.forward(b, ids)
+    l3 = chain(lambda stg, bb, x: stg.forward(bb, x), b, ids)
+    close(l3, lf, f"{family} {wdtype} 3-stage prefill with half-layer boundaries")
+    if wdtype == "bf16":
+        assert torch.equal(lf.argmax(-1), l3.argmax(-1))
+    tok = lf.argmax(-1).to(torch.int32)
+    tf = t3 = tok
+    for i in range(5):
+        b = step([1, 2], [1, 1], [300 + i, 20 + i], token_ids=None)
+        b.replay = i > 0
+        tf = full.decode_step(b, x=tf).clone()
+        t3 = chain(lambda stg, bb, x: stg.decode_step(bb, x=x), b, t3).clone()
+        if wdtype == "bf16":
+            assert torch.equal(tf, t3), f"step {i}"
+        t3 = tf.clone()                                             # teacher forcing for the fp8 run
+
+
 @pytest.mark.parametrize("mode", ["fp8", "fp8w"])
 def test_fp8_weight_stage_tracks_bf16_stage(mode):
     """fp8 (e4m3 + per-channel scale) layer weights: logits stay close to the bf16-weight stage,
