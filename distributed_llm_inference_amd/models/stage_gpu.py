@@ -331,7 +331,8 @@ class GpuStage:
             self._gemm_cfg[key] = c
         return c
 
-    def _layers(self, wk: _Work, T: int, B: int, tok_pos, tok_seq, q_start, ctx, slots, max_q: int, splits: int):
+    def _layers(self, wk: _Work, T: int, B: int, tok_pos, tok_seq, q_start, ctx, slots, max_q: int, splits: int,
+                alone: bool = False):
         """Runs this stage's decoder layers on wk.h[:T]. Returns the pending split-K partial
         (splits, bias) of the last down projection that the caller still has to fold into h
         (decode regime), or None when h is final."""
@@ -356,22 +357,25 @@ class GpuStage:
             # fused bias / residual / activation epilogues; the 256 x 256 kernel (bf16 and e4m3) splits
             # K inside the launch on shapes with fewer tiles than CUs and needs the workspace for that
             lws = wk.ws if self.wmode in ("bf16", "fp8") else None
+            # workgroups a thin GEMM is spread over: the whole chip for a step that runs alone (prefill
+            # chunk on the eager path), half of it for decode micro-batches that overlap on two streams
+            tg = 256 if alone else 1
             for li, p in enumerate(self.layers):
                 if "w_qkv" in p:            # attention block (absent from a first layer whose attention ran upstream)
                     x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
-                    self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, 1, 0)
+                    self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, tg, 0)
                     self._kvwrite(li, qkv, None, 1, None, tok_pos, tok_seq)
                     self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
-                    self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 2 if llama else 3, 1, 0)
+                    self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 2 if llama else 3, tg, 0)
                 if "w_down" not in p:       # MLP block runs on the next stage
                     continue
                 x2 = norm(None, 1, None, p["ln2_w"], p.get("ln2_b"))
                 if llama:
-                    self._gemm(wk, act, x2, p, "w_gu", None, None, lws, 2 * I, 4, 1, 0)
-                    self._gemm(wk, h, act, p, "w_down", None, h, lws, H, 2, 1, 0)
+                    self._gemm(wk, act, x2, p, "w_gu", None, None, lws, 2 * I, 4, tg, 0)
+                    self._gemm(wk, h, act, p, "w_down", None, h, lws, H, 2, tg, 0)
                 else:
-                    self._gemm(wk, act, x2, p, "w_fc", p["b_fc"], None, lws, I, 5, 1, 0)
-                    self._gemm(wk, h, act, p, "w_down", p["b_down"], h, lws, H, 3, 1, 0)
+                    self._gemm(wk, act, x2, p, "w_fc", p["b_fc"], None, lws, I, 5, tg, 0)
+                    self._gemm(wk, h, act, p, "w_down", p["b_down"], h, lws, H, 3, tg, 0)
             return None
         # decode regime: weight-streaming GEMMs write fp32 split-K partials which the NEXT kernel
         # (norm / rope) sums while it reads them anyway — no reduce launches, no bf16 round trip
@@ -459,7 +463,7 @@ class GpuStage:
             wk.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16))
         max_q = max(batch.q_lens) if batch.q_lens else 1
         pend = self._layers(wk, T, B, self.md_tok_pos[:T], self.md_tok_seq[:T], self.md_q_start[:B + 1], self.md_ctx[:B],
-                            self.md_slots[:B], max_q, 1)
+                            self.md_slots[:B], max_q, 1, alone=True)
         if not self.plan.has_head:
             self._fold(wk, T, pend)
             return wk.h[:T]

@@ -312,8 +312,10 @@ static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor w
       }
       wsp = workspace->data_ptr<float>(); wsn = workspace->numel();
     }
+    // more than 256 rows: `splitk` > 1 is the number of workgroups the caller wants a thin shape spread over
+    // (256: it runs alone; default 128: it shares the chip with another stream)
     dlia_gemm_large(out.data_ptr(), x.data_ptr(), wp.data_ptr(), bp, rp, wsp, wsn, (int)M, (int)N, (int)K,
-                    x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
+                    x.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, (int)splitk, stream);
   }
 }
 
@@ -409,7 +411,7 @@ void gemm_a8w8(Tensor out, const Tensor& xq, const Tensor& xscale, const Tensor&
       wsp = workspace->data_ptr<float>(); wsn = workspace->numel();
     }
     dlia_gemm_a8w8_large(out.data_ptr(), xq.data_ptr(), xscale.data_ptr<float>(), wp.data_ptr(), wscale.data_ptr<float>(), bp, rp,
-                         wsp, wsn, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, stream);
+                         wsp, wsn, (int)M, (int)N, (int)K, xq.stride(0), out.stride(0), ldr, (int)epi, f32 ? 1 : 0, (int)splitk, stream);
   }
 }
 

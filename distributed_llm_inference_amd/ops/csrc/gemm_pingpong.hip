@@ -39,6 +39,7 @@
 //
 // Replaces the nn.Linear calls inside HF LlamaDecoderLayer that the reference runs on CPU in fp32
 // (Worker1.py:128-137) and the lm_head (orchestration.py:141).
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -331,11 +332,13 @@ extern "C" int dlia_gemm_large_choice(int which) {
   return which < 0 ? v.load() : v.exchange(which);
 }
 
-// K splits for a shape: as many as keep the launch within `target` workgroups (default 128: half the
-// CUs — the serving path runs two micro-batches on two streams, and a thin launch shares the chip
-// with the other stream's kernels), each split at least 8 K-tiles long, at most 8 splits.
-static int pp_splitk(int M, int N, int ktiles) {
-  static const int target = [] { const char* e = getenv("DLIA_GEMM_PP_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+// K splits for a shape: as many as keep the launch within `target` workgroups, each split at least
+// 8 K-tiles long, at most 8 splits. Default target 128, half the CUs: decode runs two micro-batches
+// on two streams, and a thin launch shares the chip with the other stream's kernels. A caller that
+// runs alone (a prefill chunk) asks for 256: 2048-token Llama-3-8B prefill 28.8 -> 25.4 ms.
+static int pp_splitk(int M, int N, int ktiles, int want = 0) {
+  static const int dflt = [] { const char* e = getenv("DLIA_GEMM_PP_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+  const int target = want > 1 ? want : dflt;
   const int tiles = ((M + 255) / 256) * ((packed_ntiles(N) + 15) / 16);
   if (tiles > kPPCounters / 2) return 1;
   int s = target / tiles;
@@ -349,7 +352,7 @@ extern "C" int dlia_gemm_pingpong_splitk(int M, int N, int K) { return pp_splitk
 // other users of their front part keep them intact).
 extern "C" long dlia_gemm_pingpong_ws_floats(int M, int N, int K) {
   const long tiles = (long)((M + 255) / 256) * ((packed_ntiles(N) + 15) / 16);
-  const int s = dlia_gemm_pingpong_splitk(M, N, K);
+  const int s = std::max(pp_splitk(M, N, K / 64, 0), pp_splitk(M, N, K / 64, 256));   // whichever target a caller asks for
   return s > 1 ? tiles * (s - 1) * kPPSlab + kPPCounters : 0;
 }
 
@@ -374,7 +377,7 @@ extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream
 // last 4096 words are the arrival counters (zero when first handed over, zero after every launch).
 extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const void* bias, const void* residual,
                                 float* workspace, long ws_floats, int M, int N, int K, long ldx, long ldo, long ldr,
-                                int epi, int out_f32, hipStream_t stream) {
+                                int epi, int out_f32, int wg_target, hipStream_t stream) {
   if (M <= 0 || N <= 0) return;
   GemmParams p;
   p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = nullptr; p.xscale = nullptr; p.out = out; p.ldo = ldo;
@@ -385,8 +388,9 @@ extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const 
   p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
   p.out_f32 = out_f32; p.partial_only = 0; p.splitk = 1; p.group_n = 1; p.counters = nullptr;
   if (dlia_gemm_large_choice(-1) != 0) { dlia_gemm_rows(&p, stream); return; }
-  const int s = dlia_gemm_pingpong_splitk(M, N, K);
-  if (workspace && s > 1 && ws_floats >= dlia_gemm_pingpong_ws_floats(M, N, K)) {
+  const int s = pp_splitk(M, N, K / 64, wg_target);
+  const long tiles = (long)((M + 255) / 256) * ((p.ntiles + 15) / 16);
+  if (workspace && s > 1 && ws_floats >= tiles * (s - 1) * kPPSlab + kPPCounters) {
     p.splitk = s;
     p.counters = reinterpret_cast<int*>(workspace + ws_floats - kPPCounters);
   }
@@ -397,7 +401,8 @@ extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const 
 // xscale[M], wp from pack_weight_a8w8, wscale per packed row), more than 256 rows, K a multiple of 128.
 extern "C" void dlia_gemm_a8w8_large(void* out, const void* xq, const float* xscale, const void* wp, const float* wscale,
                                      const void* bias, const void* residual, float* workspace, long ws_floats, int M,
-                                     int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32, hipStream_t stream) {
+                                     int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32, int wg_target,
+                                     hipStream_t stream) {
   if (M <= 0 || N <= 0) return;
   GemmParams p;
   p.x = (const bf16*)xq; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = wscale; p.xscale = xscale; p.out = out; p.ldo = ldo;
@@ -408,7 +413,7 @@ extern "C" void dlia_gemm_a8w8_large(void* out, const void* xq, const float* xsc
   p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
   p.out_f32 = out_f32; p.partial_only = 0; p.splitk = 1; p.group_n = 1; p.counters = nullptr;
   if (dlia_gemm_large_choice(-1) != 0) { p.partial = nullptr; dlia_gemm_rows_f8(&p, stream); return; }
-  const int s = pp_splitk(M, N, K / 128);
+  const int s = pp_splitk(M, N, K / 128, wg_target);
   const long tiles = (long)((M + 255) / 256) * ((p.ntiles + 15) / 16);
   if (workspace && s > 1 && ws_floats >= tiles * (s - 1) * kPPSlab + kPPCounters) {
     p.splitk = s;

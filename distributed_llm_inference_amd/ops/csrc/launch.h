@@ -60,10 +60,11 @@ int dlia_gemm_rows_set_narrow(int on);
 // room for the in-launch split-K of thin shapes; its LAST 4096 words are arrival counters, zero between launches.
 void dlia_gemm_large(void* out, const void* x, const void* wp, const void* bias, const void* residual,
                      float* workspace, long ws_floats, int M, int N, int K, long ldx, long ldo, long ldr,
-                     int epi, int out_f32, hipStream_t stream);
+                     int epi, int out_f32, int wg_target, hipStream_t stream);
 extern "C" void dlia_gemm_a8w8_large(void* out, const void* xq, const float* xscale, const void* wp, const float* wscale,
                                      const void* bias, const void* residual, float* workspace, long ws_floats, int M,
-                                     int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32, hipStream_t stream);
+                                     int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32, int wg_target,
+                                     hipStream_t stream);
 // kernel for bf16 GEMMs of more than 256 rows: 0 = 256 x 256 ping-pong tiles (default), 2 = the loader-wave
 // kernel of gemm_rows.hip; which < 0 only reads; returns the previous choice
 int dlia_gemm_large_choice(int which);
