@@ -32,6 +32,8 @@ import time
 # receive waiting for its peer at the head of a shared queue stalls the compute behind it — the
 # pipeline would run one micro-batch at a time. Read by the HIP runtime when it initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# RCCL and cross-process device buffers use dmabuf IPC handles; the legacy IPC mode is not supported by the driver here
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 

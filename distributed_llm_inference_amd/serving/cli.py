@@ -17,6 +17,8 @@ import sys
 
 # more HIP streams than HIP's default 4 hardware queues per process: see bench.py
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# RCCL and cross-process device buffers use dmabuf IPC handles; the legacy IPC mode is not supported by the driver here
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from ..config import EngineConfig
 
