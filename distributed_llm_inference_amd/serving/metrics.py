@@ -33,6 +33,8 @@ def render(engine_snapshot: Dict, board=None, num_stages: int = 0) -> str:
     metric("recompositions_total", s.get("recompositions"), "micro-batch recompositions", "counter")
     metric("requests_waiting", s.get("waiting"), "requests queued")
     metric("requests_running", s.get("running"), "sequences decoding")
+    metric("preemptions_total", s.get("preemptions"), "sequences preempted for KV blocks (recomputed later)", "counter")
+    metric("kv_blocks_grown_total", s.get("kv_blocks_grown"), "KV blocks handed out on demand during decode", "counter")
     metric("kv_blocks_used", s.get("kv_blocks_used"), "KV blocks in use")
     metric("kv_blocks_total", s.get("kv_blocks_total"), "KV blocks per stage")
     metric("token_latency_ms", s.get("tpot_ms_p50"), "per-token decode latency", labels={"quantile": "0.5"})
