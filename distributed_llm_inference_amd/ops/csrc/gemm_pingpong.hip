@@ -335,7 +335,8 @@ extern "C" int dlia_gemm_large_choice(int which) {
 // K splits for a shape: as many as keep the launch within `target` workgroups, each split at least
 // 8 K-tiles long, at most 8 splits. Default target 128, half the CUs: decode runs two micro-batches
 // on two streams, and a thin launch shares the chip with the other stream's kernels. A caller that
-// runs alone (a prefill chunk) asks for 256: 2048-token Llama-3-8B prefill 28.8 -> 25.4 ms.
+// runs alone (a prefill chunk) asks for 256: 2048-token Llama-3-8B prefill 28.8 -> 25.4 ms. (Also
+// splitting the 96-tile QKV shape in two at 1024 rows: 33.3 against 32.95 ms per decode step, not kept.)
 static int pp_splitk(int M, int N, int ktiles, int want = 0) {
   static const int dflt = [] { const char* e = getenv("DLIA_GEMM_PP_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
   const int target = want > 1 ? want : dflt;
