@@ -1,0 +1,236 @@
+// Native serving loop of a single-stage pipeline's stage process.
+//
+// In steady state a decode step of a micro-batch is "the same captured graph once more": the
+// scheduler sends a 40-byte compact replay descriptor (runtime/batch.py) and wants the sampled token
+// ids back. This loop does that without entering Python: descriptor ring -> (block-table growth
+// entries: 4-byte host-to-device copies) -> hipGraphLaunch on the micro-batch's stream -> copy of the
+// token ids to pinned host memory on the same stream -> completion event -> result ring. Everything
+// else — prefill chunks, recompositions, control messages — is handed back to the Python loop
+// (runtime/head.py::head_main), which answers through the same queue so that results leave in
+// submission order and the result ring keeps its single producer.
+//
+// The reference's counterpart is the Flask request handler around model.forward
+// (Worker1.py:208-245; orchestration.py:109-196).
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <new>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t kDescMagic = 0x444C4942;     // "DLIB" (runtime/batch.py)
+constexpr uint32_t kResMagic = 0x52455331;      // "RES1" (runtime/head.py)
+constexpr int kKindStep = 1;
+constexpr uint32_t kFlagReplay = 1, kFlagCompact = 2;
+constexpr int kSlots = 8;                        // results in flight per micro-batch
+constexpr int kMaxGrow = 64;                     // growth entries handled here per step; more go to Python
+
+struct DescHead {                                // "<IiiiiiiIii"
+  uint32_t magic; int32_t kind, step_id, mb, rows, ntok, ntb; uint32_t flags; int32_t ngrow, live;
+};
+static_assert(sizeof(DescHead) == 40, "descriptor header layout");
+
+typedef int (*ring_get_fn)(void*, void*, uint32_t, int);
+typedef int (*ring_put_fn)(void*, const void*, uint32_t, int);
+
+struct Mb {
+  hipGraphExec_t exec = nullptr;
+  hipStream_t stream = nullptr;
+  const int32_t* tokens = nullptr;               // device: the graph's sampled ids
+  int rows = 0;
+  int32_t* host[kSlots] = {};
+  hipEvent_t ev[kSlots] = {};
+  int next = 0;
+};
+
+struct Pending {                                 // a submitted step whose result has not left yet
+  int step_id; int n; const int32_t* host; hipEvent_t ev;
+};
+
+struct Loop {
+  int device = 0;
+  std::vector<Mb> mbs;
+  std::deque<Pending> pending;
+  ring_get_fn rget = nullptr; ring_put_fn rput = nullptr;
+  int32_t* table = nullptr; int table_rows = 0, max_blocks = 0, num_blocks = 0;   // device block table
+  int32_t* grow_stage = nullptr; int grow_pos = 0;                                  // pinned staging for growth values
+  std::vector<uint8_t> out;
+  uint64_t native_steps = 0, handed_up = 0;
+  char err[256] = {0};
+};
+
+int fail(Loop* l, const char* what, hipError_t e) {
+  snprintf(l->err, sizeof(l->err), "%s: %s", what, hipGetErrorString(e));
+  return -1;
+}
+#define HIPCHK(l, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(l, #expr, e_); } while (0)
+
+// Sends every result at the front of the queue whose event has completed. 0 ok, -1 error.
+int drain(Loop* l, void* res_ring) {
+  while (!l->pending.empty()) {
+    Pending& p = l->pending.front();
+    if (p.ev) {
+      hipError_t q = hipEventQuery(p.ev);
+      if (q == hipErrorNotReady) return 0;
+      if (q != hipSuccess) return fail(l, "hipEventQuery", q);
+    }
+    const size_t bytes = 16 + (size_t)p.n * 4;
+    if (l->out.size() < bytes) l->out.resize(bytes);
+    uint32_t head[4] = {kResMagic, (uint32_t)p.step_id, (uint32_t)p.n, 0u};
+    memcpy(l->out.data(), head, 16);
+    if (p.n) memcpy(l->out.data() + 16, p.host, (size_t)p.n * 4);
+    if (l->rput(res_ring, l->out.data(), (uint32_t)bytes, 5000) != 0) {
+      snprintf(l->err, sizeof(l->err), "result ring: put failed");
+      return -1;
+    }
+    l->pending.pop_front();
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* dlia_replay_create(int device, int max_mbs, void* ring_get, void* ring_put) {
+  Loop* l = new (std::nothrow) Loop();
+  if (!l) return nullptr;
+  l->device = device;
+  l->mbs.resize(max_mbs > 0 ? max_mbs : 1);
+  l->rget = (ring_get_fn)ring_get; l->rput = (ring_put_fn)ring_put;
+  if (hipSetDevice(device) != hipSuccess ||
+      hipHostMalloc((void**)&l->grow_stage, 4096 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+    delete l;
+    return nullptr;
+  }
+  return l;
+}
+
+const char* dlia_replay_error(void* h) { return static_cast<Loop*>(h)->err; }
+
+// The stage's block table (device, int32 [table_rows][max_blocks]) for growth entries.
+int dlia_replay_set_table(void* h, void* table, int table_rows, int max_blocks, int num_blocks) {
+  Loop* l = static_cast<Loop*>(h);
+  l->table = (int32_t*)table; l->table_rows = table_rows; l->max_blocks = max_blocks; l->num_blocks = num_blocks;
+  return 0;
+}
+
+// Registers (or replaces) the captured decode step of micro-batch `mb`: its executable graph, the
+// stream it runs on, where its sampled ids land and how many there are. exec == null unregisters.
+int dlia_replay_set_mb(void* h, int mb, void* exec, void* stream, const void* tokens, int rows) {
+  Loop* l = static_cast<Loop*>(h);
+  if (mb < 0 || mb >= (int)l->mbs.size()) { snprintf(l->err, sizeof(l->err), "micro-batch %d out of range", mb); return -1; }
+  Mb& m = l->mbs[mb];
+  if (m.rows != rows) {
+    for (int i = 0; i < kSlots; ++i) {
+      if (m.host[i]) { (void)hipHostFree(m.host[i]); m.host[i] = nullptr; }
+      if (!m.ev[i]) HIPCHK(l, hipEventCreateWithFlags(&m.ev[i], hipEventDisableTiming));
+      if (rows > 0) HIPCHK(l, hipHostMalloc((void**)&m.host[i], (size_t)rows * 4, hipHostMallocDefault));
+    }
+  }
+  m.exec = (hipGraphExec_t)exec; m.stream = (hipStream_t)stream; m.tokens = (const int32_t*)tokens; m.rows = rows;
+  return 0;
+}
+
+// A step the Python loop ran itself: its result joins the queue behind the native ones. `event`
+// (a HIP event handle, may be null = already complete) guards `host` (n ids, stays valid until sent).
+int dlia_replay_push_external(void* h, int step_id, void* event, const void* host, int n) {
+  Loop* l = static_cast<Loop*>(h);
+  l->pending.push_back(Pending{step_id, n, (const int32_t*)host, (hipEvent_t)event});
+  return 0;
+}
+
+int dlia_replay_pending(void* h) { return (int)static_cast<Loop*>(h)->pending.size(); }
+
+void dlia_replay_stats(void* h, uint64_t* out2) {
+  Loop* l = static_cast<Loop*>(h);
+  out2[0] = l->native_steps; out2[1] = l->handed_up;
+}
+
+// Serves the descriptor ring until a message arrives that Python has to handle (returns 1, message
+// in msg_out / *len), `idle_ms` pass without one (0), or something fails (-1, dlia_replay_error; -2:
+// the descriptor ring was closed). Results of finished steps leave while it waits.
+int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, uint32_t cap, uint32_t* len, int idle_ms) {
+  Loop* l = static_cast<Loop*>(h);
+  if (hipSetDevice(l->device) != hipSuccess) return -1;
+  auto t0 = std::chrono::steady_clock::now();
+  int idle_spins = 0;
+  for (;;) {
+    if (drain(l, res_ring) != 0) return -1;
+    const int n = l->rget(cin_ring, msg_out, cap, 0);
+    if (n == -3) return -2;                                   // closed and drained
+    if (n == -2) { snprintf(l->err, sizeof(l->err), "descriptor larger than the message buffer"); return -1; }
+    if (n < 0) {                                              // nothing there
+      if (++idle_spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(l->pending.empty() ? 100 : 20));
+      else std::this_thread::yield();
+      if (idle_ms >= 0 && l->pending.empty() &&
+          std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= idle_ms)
+        return 0;
+      continue;
+    }
+    idle_spins = 0;
+    t0 = std::chrono::steady_clock::now();
+    const DescHead* d = static_cast<const DescHead*>(msg_out);
+    bool native = (size_t)n >= sizeof(DescHead) && d->magic == kDescMagic && d->kind == kKindStep &&
+                  (d->flags & kFlagCompact) && (d->flags & kFlagReplay) && d->mb >= 0 && d->mb < (int)l->mbs.size() &&
+                  d->ngrow >= 0 && d->ngrow <= kMaxGrow && (size_t)n >= sizeof(DescHead) + (size_t)d->ngrow * 12;
+    if (native) {
+      const Mb& m = l->mbs[d->mb];
+      native = m.exec != nullptr && m.rows == d->rows && (d->ngrow == 0 || l->table != nullptr);
+    }
+    if (!native) {
+      *len = (uint32_t)n;
+      l->handed_up++;
+      return 1;
+    }
+    Mb& m = l->mbs[d->mb];
+    // block-table growth: table[slot][pos] = block, checked like the Python path (a bad entry is skipped)
+    const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
+    for (int i = 0; i < d->ngrow; ++i) {
+      const int slot = g[i], pos = g[d->ngrow + i], blk = g[2 * d->ngrow + i];
+      if (slot < 0 || slot >= l->table_rows || pos < 0 || pos >= l->max_blocks || blk < 0 || blk >= l->num_blocks) continue;
+      int32_t* src = l->grow_stage + (l->grow_pos++ & 4095);
+      *src = blk;
+      HIPCHK(l, hipMemcpyAsync(l->table + (size_t)slot * l->max_blocks + pos, src, 4, hipMemcpyHostToDevice, m.stream));
+    }
+    const int s = m.next; m.next = (m.next + 1) % kSlots;
+    if (hipEventQuery(m.ev[s]) == hipErrorNotReady) HIPCHK(l, hipEventSynchronize(m.ev[s]));   // slot still in flight (never in practice)
+    HIPCHK(l, hipGraphLaunch(m.exec, m.stream));
+    HIPCHK(l, hipMemcpyAsync(m.host[s], m.tokens, (size_t)m.rows * 4, hipMemcpyDeviceToHost, m.stream));
+    HIPCHK(l, hipEventRecord(m.ev[s], m.stream));
+    l->pending.push_back(Pending{d->step_id, m.rows, m.host[s], m.ev[s]});
+    l->native_steps++;
+  }
+}
+
+// Blocks until every queued result has left (or `timeout_ms` passed: returns 1).
+int dlia_replay_flush(void* h, void* res_ring, int timeout_ms) {
+  Loop* l = static_cast<Loop*>(h);
+  auto t0 = std::chrono::steady_clock::now();
+  while (!l->pending.empty()) {
+    if (drain(l, res_ring) != 0) return -1;
+    if (l->pending.empty()) break;
+    if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= timeout_ms) return 1;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  return 0;
+}
+
+void dlia_replay_destroy(void* h) {
+  Loop* l = static_cast<Loop*>(h);
+  for (Mb& m : l->mbs)
+    for (int i = 0; i < kSlots; ++i) {
+      if (m.host[i]) (void)hipHostFree(m.host[i]);
+      if (m.ev[i]) (void)hipEventDestroy(m.ev[i]);
+    }
+  if (l->grow_stage) (void)hipHostFree(l->grow_stage);
+  delete l;
+}
+
+}  // extern "C"

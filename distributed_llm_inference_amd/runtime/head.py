@@ -258,12 +258,110 @@ class RemoteHead:
             pass
 
 
+def _native_replay_for(runtime, cin, res):
+    """The native serving loop, when this stage process is a whole single-stage pipeline on a GPU
+    that runs captured decode graphs over shared-memory rings (DLIA_NATIVE_LOOP=0 turns it off)."""
+    import os
+    if os.environ.get("DLIA_NATIVE_LOOP", "1") == "0":
+        return None
+    ex = runtime.ex
+    if not (runtime.on_gpu and runtime.links.num_stages == 1 and hasattr(ex, "decode_step") and getattr(ex, "use_graphs", False)
+            and not runtime.debug_top5 and runtime.tracer is None and hasattr(cin, "ring") and hasattr(res, "ring")):
+        return None
+    from .replay import NativeReplay
+    dev = torch.device(runtime.device)
+    nr = NativeReplay(dev.index if dev.index is not None else torch.cuda.current_device(), getattr(ex, "decode_states", 1) + 64,
+                      cin.ring, res.ring)
+    nr.set_table(ex.block_table, ex.num_blocks)
+    return nr
+
+
+def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
+    """`head_main` around the native loop: C++ serves replay steps, Python whatever else arrives;
+    Python's results join the native queue so they leave in submission order."""
+    from collections import deque
+    from ..parallel.shm import ST_ERROR, ST_READY, ST_STOPPED
+    board, ex = runtime.board, runtime.ex
+    keep = deque(maxlen=256)             # results (pinned buffers, events) referenced by the native queue
+    counted = 0
+
+    def account():
+        nonlocal counted
+        n = nr.stats()["native_steps"]
+        if n > counted:
+            runtime.steps += n - counted
+            if board is not None:
+                board.beat(runtime.stage, n - counted, 0, 0)
+            counted = n
+
+    if board is not None:
+        board.set_state(runtime.stage, ST_READY)
+    step_id = -1
+    try:
+        while True:
+            rc, msg = nr.serve(int(idle_beat_s * 1000))
+            account()
+            if rc == -2:
+                break
+            if rc == 0:
+                if board is not None:
+                    board.beat(runtime.stage)
+                continue
+            desc = StepBatch.from_bytes(msg)
+            if desc.kind == KIND_SHUTDOWN:
+                nr.flush()
+                head.shutdown()
+                break
+            if desc.kind != KIND_STEP:
+                head.control(desc)
+                continue
+            step_id = desc.step_id
+            r = head.submit(desc)
+            n = runtime.result_count(desc)
+            keep.append(r)
+            nr.push_external(step_id, r.event.cuda_event if r.event is not None else None, r.host.data_ptr() if n else 0, n)
+            if runtime._graph_decode(desc) and not desc.replay:
+                # (re)register the micro-batch's captured step: graph, stream, where its ids land
+                st = ex._mb_state(desc.micro_batch, desc.num_seqs)
+                if st.graph is not None:
+                    nr.set_mb(desc.micro_batch, st.graph.raw_cuda_graph_exec(), runtime._stream_of(desc).cuda_stream,
+                              st.tokens.data_ptr(), desc.num_seqs)
+    except BaseException as e:
+        if board is not None:
+            board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
+        try:
+            res.put(pack_result(step_id if isinstance(e, Exception) else -1, [], f"{type(e).__name__}: {e}"))
+            res.put(pack_result(-1, [], f"{type(e).__name__}: {e}"))
+        except Exception:
+            pass
+        runtime.abort()
+        raise
+    finally:
+        try:
+            import json
+            import os
+            path = os.environ.get("DLIA_NATIVE_LOOP_STATS")        # tests / benches: how many steps never entered Python
+            if path:
+                with open(path, "w") as f:
+                    json.dump(nr.stats(), f)
+            nr.close()
+        except Exception:
+            pass
+    if board is not None:
+        board.set_state(runtime.stage, ST_STOPPED)
+    return runtime.steps
+
+
 def head_main(runtime, cin, res, idle_beat_s: float = 0.5) -> int:
     """Loop of a stage-0 process serving a `RemoteHead`: descriptors in, token ids out, until
     SHUTDOWN. A forwarder thread waits for each step's tokens (device event / feedback receive) in
-    submission order, so the descriptor loop itself never blocks on the device."""
+    submission order, so the descriptor loop itself never blocks on the device. A single-stage GPU
+    pipeline runs the loop natively instead (`runtime/replay.py`)."""
     from ..parallel.shm import ST_ERROR, ST_READY, ST_STOPPED, RingClosed
     head = LocalHead(runtime)
+    nr = _native_replay_for(runtime, cin, res)
+    if nr is not None:
+        return _head_main_native(runtime, head, nr, cin, res, idle_beat_s)
     board = runtime.board
     pending: "queue.Queue" = queue.Queue()
     failed = threading.Event()

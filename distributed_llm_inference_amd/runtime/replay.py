@@ -1,0 +1,92 @@
+"""ctypes front of the native serving loop (`ops/csrc/comm/replay_loop.cpp` -> `ops/_comm.so`).
+
+`NativeReplay.serve()` blocks inside C++ (the GIL is released) and handles the steady state of a
+single-stage pipeline — compact replay descriptors in, hipGraph launch, token ids out — returning to
+Python only for messages that need it. See `runtime/head.py::head_main`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+_sigs_done = False
+
+
+def _lib():
+    global _sigs_done
+    from ..parallel import rccl
+    L = rccl.lib()
+    if not _sigs_done:
+        vp, ci, u32 = C.c_void_p, C.c_int, C.c_uint32
+        sig = {
+            "dlia_replay_create": (vp, [ci, ci, vp, vp]),
+            "dlia_replay_error": (C.c_char_p, [vp]),
+            "dlia_replay_set_table": (ci, [vp, vp, ci, ci, ci]),
+            "dlia_replay_set_mb": (ci, [vp, ci, vp, vp, vp, ci]),
+            "dlia_replay_push_external": (ci, [vp, ci, vp, vp, ci]),
+            "dlia_replay_pending": (ci, [vp]),
+            "dlia_replay_stats": (None, [vp, C.POINTER(C.c_uint64)]),
+            "dlia_replay_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
+            "dlia_replay_flush": (ci, [vp, vp, ci]),
+            "dlia_replay_destroy": (None, [vp]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _sigs_done = True
+    return L
+
+
+class NativeReplayError(RuntimeError):
+    pass
+
+
+class NativeReplay:
+    """`cin` / `res`: the `ShmRing`s of the descriptor and result rings (this process consumes the
+    first and is the only producer of the second)."""
+
+    def __init__(self, device_index: int, max_mbs: int, cin, res):
+        from ..utils import native
+        self.L = _lib()
+        rt = native.lib()
+        self.cin, self.res = cin, res
+        self.h = self.L.dlia_replay_create(device_index, max_mbs, C.cast(rt.dlia_ring_get, C.c_void_p),
+                                           C.cast(rt.dlia_ring_put, C.c_void_p))
+        if not self.h:
+            raise NativeReplayError("cannot create the native serving loop")
+        self._buf = C.create_string_buffer(cin.slot_bytes)
+        self._len = C.c_uint32(0)
+
+    def _check(self, rc: int, what: str) -> int:
+        if rc == -1:
+            raise NativeReplayError(f"{what}: {self.L.dlia_replay_error(self.h).decode(errors='replace')}")
+        return rc
+
+    def set_table(self, table, num_blocks: int):
+        self._check(self.L.dlia_replay_set_table(self.h, table.data_ptr(), table.shape[0], table.shape[1], num_blocks), "set_table")
+
+    def set_mb(self, mb: int, graph_exec: int, stream: int, tokens_ptr: int, rows: int):
+        self._check(self.L.dlia_replay_set_mb(self.h, mb, C.c_void_p(graph_exec), C.c_void_p(stream), C.c_void_p(tokens_ptr), rows),
+                    "set_mb")
+
+    def push_external(self, step_id: int, event: Optional[int], host_ptr: int, n: int):
+        self.L.dlia_replay_push_external(self.h, step_id, C.c_void_p(event) if event else None, C.c_void_p(host_ptr), n)
+
+    def serve(self, idle_ms: int) -> Tuple[int, Optional[bytes]]:
+        """(1, message for Python) | (0, None) after `idle_ms` without one | (-2, None) ring closed."""
+        rc = self._check(self.L.dlia_replay_serve(self.h, self.cin._h, self.res._h, self._buf, self.cin.slot_bytes,
+                                                  C.byref(self._len), idle_ms), "native serving loop")
+        return rc, (self._buf.raw[:self._len.value] if rc == 1 else None)
+
+    def flush(self, timeout_s: float = 30.0) -> bool:
+        return self._check(self.L.dlia_replay_flush(self.h, self.res._h, int(timeout_s * 1000)), "flush") == 0
+
+    def stats(self):
+        out = (C.c_uint64 * 2)()
+        self.L.dlia_replay_stats(self.h, out)
+        return {"native_steps": int(out[0]), "handed_to_python": int(out[1])}
+
+    def close(self):
+        if self.h:
+            self.L.dlia_replay_destroy(self.h)
+            self.h = None

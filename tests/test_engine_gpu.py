@@ -357,3 +357,37 @@ def test_decode_graph_is_captured_once_across_recompositions_on_a_two_stage_pipe
             assert len(ex._mbs) <= c.num_micro_batches
     finally:
         pipe.close()
+
+
+def test_single_stage_process_serves_replay_steps_natively(tmp_path, monkeypatch):
+    """`isolate`: the one stage lives in a child process whose loop is C++ in steady state (descriptor
+    ring -> block-table growth -> hipGraphLaunch -> token copy -> result ring). Same tokens as the
+    in-process engine, prompts long enough to cross 32-token block boundaries while decoding (growth
+    entries on replay descriptors), more requests than rows (recompositions hand control back to
+    Python and forth), and the child reports that most steps never entered Python."""
+    import json
+    from distributed_llm_inference_amd.parallel.launcher import make_pipeline
+
+    def run_isolated(c):
+        pipe = make_pipeline(c)
+        try:
+            pipe.wait_ready(timeout=240)
+            reqs = [pipe.engine.submit(p, greedy(48)) for p in ps]
+            outs = [r.wait(300).output for r in reqs]
+            pipe.engine.wait_idle()
+            return outs, pipe.engine.snapshot()
+        finally:
+            pipe.close()
+
+    ps = [p * 3 for p in prompts(20, seed=21)]
+    want, _ = run(cfg(max_seq_len=256), ps, greedy(48))
+    stats = tmp_path / "native.json"
+    monkeypatch.setenv("DLIA_NATIVE_LOOP_STATS", str(stats))
+    got, snap = run_isolated(cfg(max_seq_len=256, isolate=True))
+    assert got == want and snap["fatal"] is None and snap["failed"] == 0
+    st = json.loads(stats.read_text())
+    assert st["native_steps"] > 3 * st["handed_to_python"] > 0, st
+    monkeypatch.setenv("DLIA_NATIVE_LOOP", "0")                       # and the Python loop still gives the same
+    stats.unlink()
+    again, _ = run_isolated(cfg(max_seq_len=256, isolate=True))
+    assert again == want and not stats.exists()
