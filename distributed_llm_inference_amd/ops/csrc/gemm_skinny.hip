@@ -559,8 +559,13 @@ extern "C" void dlia_gemm_skinny_config(int M, int N, int K, int epi, int allow_
     while (nblocks * s < target && s < 16 && chunks / (s * 2) >= 2) s *= 2;
     const double cap = M > 128 ? 36.0e6 : 20.0e6;                  // cap the fp32 partial traffic
     while (s > 1 && (double)s * M * N * 4.0 > cap) s /= 2;
+    // A fused epilogue (bias / residual / activation: anything but "partials only") needs a reduce
+    // launch after a split, ~5 us of a decode step that is a chain of ~5 us kernels. From 64
+    // workgroups on, the unsplit launch is faster than split + reduce: TinyLlama gate/up (88
+    // workgroups unsplit, 4 splits before) 1.155 -> 1.113 ms per token at batch 1, 1.66 -> 1.54 at 64;
+    // GPT-2's fc (24 workgroups) keeps its split (0.507 against 0.518 ms unsplit).
+    if (epi != 6 && nblocks >= 64) s = 1;
   }
-  (void)epi;
   *ntw_out = ntw; *splitk_out = s;
 }
 
