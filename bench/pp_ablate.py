@@ -1,0 +1,96 @@
+"""Ablation timing of the 256 x 256 ping-pong GEMM: diagnostic builds of gemm_pingpong.hip with parts
+of the main loop left out (PP_ABL mask: 1 DMA issue, 2 fragment reads, 4 barriers, 8 MFMAs), timed on
+the Llama-3-8B layer shapes. The outputs of an ablated build are wrong on purpose; the times say what
+the remaining parts cost. Build on the CPU box first (`--build`), run on the GPU.
+
+    python bench/pp_ablate.py --build            # compiles bench/build/pp_abl_<mask>.so for every mask
+    python bench/pp_ablate.py --m 4096
+"""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "distributed_llm_inference_amd", "ops", "csrc")
+OUT = os.path.join(HERE, "build")
+MASKS = [0, 1, 2, 3, 4, 8, 9, 10, 12]
+
+
+def so_path(mask):
+    return os.path.join(OUT, f"pp_abl_{mask}.so")
+
+
+def build(masks):
+    os.makedirs(OUT, exist_ok=True)
+    procs = []
+    for m in masks:
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+               f"-DPP_ABL={m}", os.path.join(CSRC, "gemm_pingpong.hip"), os.path.join(CSRC, "gemm_rows.hip"),
+               "-o", so_path(m)]
+        procs.append((m, subprocess.Popen(cmd)))
+        if len(procs) >= 4:
+            for mm, p in procs:
+                assert p.wait() == 0, mm
+            procs = []
+    for mm, p in procs:
+        assert p.wait() == 0, mm
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build", action="store_true")
+    ap.add_argument("--m", type=int, nargs="+", default=[4096])
+    ap.add_argument("--masks", type=int, nargs="+", default=MASKS)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--pad", type=int, nargs="+", default=[0], help="extra elements per x row (row stride K + pad): L2 channel spread")
+    a = ap.parse_args()
+    if a.build:
+        build(a.masks)
+        return
+    import torch
+    sys.path.insert(0, ROOT)
+    from distributed_llm_inference_amd.ops import packing
+    shapes = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336)]
+    vp = C.c_void_p
+    for M, pad in [(m, p) for m in a.m for p in a.pad]:
+        data = {}
+        for name, N, K in shapes:
+            x = torch.randn(M, K + pad, device="cuda").to(torch.bfloat16)
+            wp = packing.pack_weight((torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16))
+            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            data[name] = (x, wp, out)
+        for mask in a.masks:
+            L = C.CDLL(so_path(mask))
+            f = L.dlia_gemm_large
+            f.restype = None
+            f.argtypes = [vp, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
+                          C.c_int, C.c_int, C.c_int, vp]
+            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA")) if mask & b) + ")"]
+            tt, tf = 0.0, 0.0
+            for name, N, K in shapes:
+                x, wp, out = data[name]
+                st = torch.cuda.current_stream().cuda_stream
+
+                def run():
+                    f(out.data_ptr(), x.data_ptr(), wp.data_ptr(), None, None, None, 0, M, N, K, K + pad, N, 0, 0, 0, 0, vp(st))
+                for _ in range(3):
+                    run()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                for _ in range(a.iters):
+                    run()
+                ev[1].record()
+                torch.cuda.synchronize()
+                t = ev[0].elapsed_time(ev[1]) / a.iters * 1e-3
+                fl = 2.0 * M * N * K
+                tt += t; tf += fl
+                line.append(f"{name} {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}T")
+            line.append(f"layer {tt * 1e6:7.1f}us {tf / tt / 1e12:6.0f}T")
+            print("  ".join(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

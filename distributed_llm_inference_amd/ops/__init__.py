@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_C.so")
+# DLIA_OPS_LIB: another build of the same library (same-box A/B runs of a kernel variant, bench/ab_build.py)
+_LIB = os.environ.get("DLIA_OPS_LIB") or os.path.join(_HERE, "_C.so")
 _loaded = False
 
 

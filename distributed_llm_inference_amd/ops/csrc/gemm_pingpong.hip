@@ -47,6 +47,13 @@
 #include "gemm_common.h"
 #include "launch.h"
 
+// Diagnostic builds only (bench/pp_ablate.py): PP_ABL is a mask of parts of the main loop to leave
+// out — 1 DMA issue, 2 fragment reads, 4 barriers, 8 MFMAs. Results are then wrong on purpose; what
+// is measured is what the remaining parts cost. The library is always built with 0.
+#ifndef PP_ABL
+#define PP_ABL 0
+#endif
+
 namespace dlia {
 
 constexpr int kPPThreads = 512;
@@ -72,6 +79,10 @@ __device__ __forceinline__ void pp_barrier() {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void pp_loop_barrier() {
+  if constexpr (!(PP_ABL & 4)) pp_barrier();
+  else __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int V> using ic = std::integral_constant<int, V>;
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
       for (int kk = 0; kk < 2; ++kk) bf[j][kk] = *reinterpret_cast<const u32x4*>(base + (j * 2 + kk) * 1024);
   };
   auto cluster = [&](f32x4 (&c)[4][2], const u32x4 (&bf)[2][2]) {
+    if constexpr (PP_ABL & 8) return;
     __builtin_amdgcn_s_setprio(1);
     if constexpr (F8) {
       auto join = [](const u32x4& lo, const u32x4& hi) {
@@ -201,21 +213,25 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   auto phase = [&](auto q_c, int t, int par) {
     constexpr int q = decltype(q_c)::value;
     if constexpr (q == 3) pp_wait_vm<2>();       // my pieces of K-tile t + 1 have landed (A0 of t + 2 may be in flight)
-    if constexpr (q == 0) { read_b(par, ic<0>{}, b0); __builtin_amdgcn_sched_barrier(0); read_a(par, ic<0>{}); }
-    if constexpr (q == 1) read_b(par, ic<1>{}, b1);
-    if constexpr (q == 2) read_a(par, ic<1>{});
+    if constexpr (!(PP_ABL & 2)) {
+      if constexpr (q == 0) { read_b(par, ic<0>{}, b0); __builtin_amdgcn_sched_barrier(0); read_a(par, ic<0>{}); }
+      if constexpr (q == 1) read_b(par, ic<1>{}, b1);
+      if constexpr (q == 2) read_a(par, ic<1>{});
+    }
     __builtin_amdgcn_sched_barrier(0);
     // half-tile number 4 t + q + 6
-    if constexpr (q == 0) issue(ic<2>{}, t + 1, par ^ 1);
-    if constexpr (q == 1) issue(ic<3>{}, t + 1, par ^ 1);
-    if constexpr (q == 2) issue(ic<0>{}, t + 2, par);
-    if constexpr (q == 3) issue(ic<1>{}, t + 2, par);
-    pp_barrier();
+    if constexpr (!(PP_ABL & 1)) {
+      if constexpr (q == 0) issue(ic<2>{}, t + 1, par ^ 1);
+      if constexpr (q == 1) issue(ic<3>{}, t + 1, par ^ 1);
+      if constexpr (q == 2) issue(ic<0>{}, t + 2, par);
+      if constexpr (q == 3) issue(ic<1>{}, t + 2, par);
+    }
+    pp_loop_barrier();
     if constexpr (q == 0) cluster(acc[0][0], b0);
     if constexpr (q == 1) cluster(acc[0][1], b1);
     if constexpr (q == 2) cluster(acc[1][1], b1);
     if constexpr (q == 3) cluster(acc[1][0], b0);
-    pp_barrier();
+    pp_loop_barrier();
   };
 
   // prologue: K-tile 0 whole, A0 and B0 of K-tile 1
@@ -223,7 +239,10 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   issue(ic<0>{}, 1, 1); issue(ic<1>{}, 1, 1);
   pp_wait_vm<4>();                               // K-tile 0 has landed (my pieces)
   pp_barrier();                                  // ... and everyone's
-  if (wr == 1) pp_barrier();                     // waves 4-7 run one interval behind
+  if constexpr (PP_ABL & 2) {                    // diagnostic: fragments read once, outside the loop
+    read_b(0, ic<0>{}, b0); read_b(0, ic<1>{}, b1); read_a(0, ic<0>{});
+  }
+  if (wr == 1) pp_loop_barrier();                // waves 4-7 run one interval behind
 
   for (int t = 0; t < n; t += 2) {
     phase(ic<0>{}, t, 0); phase(ic<1>{}, t, 0); phase(ic<2>{}, t, 0); phase(ic<3>{}, t, 0);
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
       phase(ic<0>{}, t + 1, 1); phase(ic<1>{}, t + 1, 1); phase(ic<2>{}, t + 1, 1); phase(ic<3>{}, t + 1, 1);
     }
   }
-  if (wr == 0) pp_barrier();                     // the barrier waves 4-7 took at the start
+  if (wr == 0) pp_loop_barrier();                // the barrier waves 4-7 took at the start
   pp_wait_vm<0>();                               // no DMA may land after the workgroup is gone
 
   if (p.splitk > 1) {
