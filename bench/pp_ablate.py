@@ -68,7 +68,7 @@ def main():
             f.restype = None
             f.argtypes = [vp, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
                           C.c_int, C.c_int, C.c_int, vp]
-            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA")) if mask & b) + ")"]
+            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile")) if mask & b) + ")"]
             tt, tf = 0.0, 0.0
             for name, N, K in shapes:
                 x, wp, out = data[name]

@@ -62,13 +62,18 @@ constexpr int kPPLds = 8 * kPPHalf;              // 2 K-tiles x {A0, B0, B1, A1}
 constexpr int kPPSlab = 256 * 256;               // floats of one partial tile
 constexpr int kPPCounters = 4096;                // counter words at the end of the workspace (two per output tile)
 
-// 16 B per lane, global -> LDS: lane l lands at lds_addr + 16 l. M0 carries the wave-uniform LDS
-// address and is restored, since the compiler does not expect inline asm to change it.
-__device__ __forceinline__ void pp_dma16(const void* gptr, unsigned lds_addr) {
-  unsigned saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-               "s_nop 0\n\ts_mov_b32 m0, %0"
-               : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
+// Two 1 KiB pieces, global -> LDS, under ONE setting of M0: lane l of piece i lands at
+// lds_addr + 1024 i + 16 l and reads g_i + 16 bytes per lane as set up by the caller. The second
+// piece uses the instruction's immediate offset, which advances the global AND the LDS address, so
+// its source pointer is passed 1024 bytes low. Why one setting: a write to M0 waits until every
+// earlier LDS-DMA instruction of the wave has read it, ~180 cycles after issue — with M0 written
+// (and restored) around every piece a wave issues one piece per ~180 cycles and a CU takes 32 bytes
+// per cycle from L2, with four pieces per setting 63 (bench/l2_lds_bw.hip). M0 is not restored:
+// nothing else in this kernel uses it (no other LDS-DMA, no indexed register access).
+__device__ __forceinline__ void pp_dma_pair(const void* g0, const void* g1_minus_1k, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+               "global_load_lds_dwordx4 %2, off offset:1024"
+               :: "s"(lds_addr), "v"(g0), "v"(g1_minus_1k) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void pp_wait_vm() {
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   const int n = min(tiles_total, c0 + per) - c0;   // K-tiles of this split (>= 1 by the launcher)
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
 
+  // diagnostic mask 16: every workgroup of an XCD loads the same two panels (all L2 hits)
+  const int cb_l = (PP_ABL & 16) ? (int)(blockIdx.x & 7) : cb, mrow0_l = (PP_ABL & 16) ? 0 : mrow0;
   // ---- DMA sources: per half-tile this wave moves pieces 2 wave and 2 wave + 1 -----------------
   // x piece: 8 rows x 128 B (rows past M re-read the last row; never stored). weight piece: one
   // (n-tile, k-step) block; a column half past the packed width re-reads n-tile `wave` (never stored).
@@ -130,12 +137,13 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
     for (int e = 0; e < 2; ++e) {
       const int r = 16 * wave + 8 * e + (lane >> 3);
       const int slot = (lane & 7) ^ ((r >> 1) & 7);
-      asrc[h][e] = reinterpret_cast<const char*>(p.x) + (long)min(mrow0 + h * 128 + r, p.M - 1) * ldxb + slot * 16 + (long)c0 * 128;
+      asrc[h][e] = reinterpret_cast<const char*>(p.x) + (long)min(mrow0_l + h * 128 + r, p.M - 1) * ldxb + slot * 16 + (long)c0 * 128
+                   - e * 1024;                     // the second piece of a pair is issued with offset:1024
     }
   const char* bsrc[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int nt = cb * 16 + h * 8 + wave;
+    const int nt = cb_l * 16 + h * 8 + wave;
     bsrc[h] = reinterpret_cast<const char*>(p.wp) + ((long)(nt < p.ntiles ? nt : wave) * KT + (long)c0 * 2) * 1024 + lane * 16;
   }
   // kind: 0 A0, 1 B0, 2 B1, 3 A1 (the order of the stream); c = K-tile of this split; par = its LDS buffer
@@ -145,12 +153,11 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
     const unsigned dst = lds0 + (par * 4 + kind) * kPPHalf + wave * 2048;
     if constexpr (kind == 0 || kind == 3) {
       constexpr int h = kind == 3 ? 1 : 0;
-      pp_dma16(asrc[h][0] + (long)cc * 128, dst);
-      pp_dma16(asrc[h][1] + (long)cc * 128, dst + 1024);
+      pp_dma_pair(asrc[h][0] + (long)cc * 128, asrc[h][1] + (long)cc * 128, dst);
     } else {
       constexpr int h = kind == 2 ? 1 : 0;
-      pp_dma16(bsrc[h] + (long)cc * 2048, dst);
-      pp_dma16(bsrc[h] + (long)cc * 2048 + 1024, dst + 1024);
+      const char* g = bsrc[h] + (long)cc * 2048;
+      pp_dma_pair(g, g, dst);
     }
   };
 
