@@ -68,14 +68,17 @@ def main():
             f.restype = None
             f.argtypes = [vp, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
                           C.c_int, C.c_int, C.c_int, vp]
-            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile")) if mask & b) + ")"]
+            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile"), (32, "stamps")) if mask & b) + ")"]
             tt, tf = 0.0, 0.0
             for name, N, K in shapes:
                 x, wp, out = data[name]
                 st = torch.cuda.current_stream().cuda_stream
 
+                stamps = torch.zeros(((M + 255) // 256) * ((N + 2047) // 2048 * 8) * 8 * 16 + 64, device="cuda", dtype=torch.int32) if mask & 32 else None
+
                 def run():
-                    f(out.data_ptr(), x.data_ptr(), wp.data_ptr(), None, None, None, 0, M, N, K, K + pad, N, 0, 0, 0, 0, vp(st))
+                    f(out.data_ptr(), x.data_ptr(), wp.data_ptr(), None, None, stamps.data_ptr() if stamps is not None else None,
+                      0, M, N, K, K + pad, N, 0, 0, 0, 0, vp(st))
                 for _ in range(3):
                     run()
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -88,6 +91,15 @@ def main():
                 fl = 2.0 * M * N * K
                 tt += t; tf += fl
                 line.append(f"{name} {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}T")
+                if stamps is not None:
+                    v = stamps[:-64].view(-1, 8, 4, 4).float()
+                    v = v[v.sum(dim=(1, 2, 3)) > 0]                 # workgroups that ran (the grid is padded)
+                    ktiles = K // 64
+                    for grp, name_g in ((slice(0, 4), "waves 0-3"), (slice(4, 8), "waves 4-7")):
+                        m = v[:, grp].mean(dim=(0, 1)) / ktiles      # cycles per phase, [kind][segment]
+                        print(f"    {name} {name_g}: cycles per phase (reads+DMA | barrier 1 | cluster | barrier 2): " +
+                              "  ".join(f"q{q}: " + " | ".join(f"{m[q, sgm].item():5.0f}" for sgm in range(4)) for q in range(4)) +
+                              f"   K-tile total {m.sum().item():6.0f}", flush=True)
             line.append(f"layer {tt * 1e6:7.1f}us {tf / tt / 1e12:6.0f}T")
             print("  ".join(line), flush=True)
 

@@ -217,8 +217,12 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   };
 
   // One phase = [fragment reads + DMA issue] barrier [MFMA cluster] barrier. t = K-tile, par = t & 1.
+  unsigned stamp_sum[4][4] = {};                 // diagnostic (PP_ABL & 32): [phase kind][segment]
+  unsigned long long stamp_prev = 0;
   auto phase = [&](auto q_c, int t, int par) {
     constexpr int q = decltype(q_c)::value;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if constexpr (PP_ABL & 32) s0 = __builtin_amdgcn_s_memtime();
     if constexpr (q == 3) pp_wait_vm<2>();       // my pieces of K-tile t + 1 have landed (A0 of t + 2 may be in flight)
     if constexpr (!(PP_ABL & 2)) {
       if constexpr (q == 0) { read_b(par, ic<0>{}, b0); __builtin_amdgcn_sched_barrier(0); read_a(par, ic<0>{}); }
@@ -233,11 +237,24 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
       if constexpr (q == 2) issue(ic<0>{}, t + 2, par);
       if constexpr (q == 3) issue(ic<1>{}, t + 2, par);
     }
+    if constexpr (PP_ABL & 32) s1 = __builtin_amdgcn_s_memtime();
     pp_loop_barrier();
+    if constexpr (PP_ABL & 32) s2 = __builtin_amdgcn_s_memtime();
     if constexpr (q == 0) cluster(acc[0][0], b0);
     if constexpr (q == 1) cluster(acc[0][1], b1);
     if constexpr (q == 2) cluster(acc[1][1], b1);
     if constexpr (q == 3) cluster(acc[1][0], b0);
+    if constexpr (PP_ABL & 32) {
+      __builtin_amdgcn_sched_barrier(0);
+      s3 = __builtin_amdgcn_s_memtime();
+      // the previous phase's second barrier ended at this phase's s0
+      if (stamp_prev) stamp_sum[(q + 3) & 3][3] += (unsigned)(s0 - stamp_prev);
+      stamp_sum[q][0] += (unsigned)(s1 - s0);
+      stamp_sum[q][1] += (unsigned)(s2 - s1);
+      stamp_sum[q][2] += (unsigned)(s3 - s2);
+      stamp_prev = s3;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     pp_loop_barrier();
   };
 
@@ -260,6 +277,15 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
   if (wr == 0) pp_loop_barrier();                // the barrier waves 4-7 took at the start
   pp_wait_vm<0>();                               // no DMA may land after the workgroup is gone
 
+  if constexpr (PP_ABL & 32) {
+    if (lane == 0 && p.partial != nullptr) {
+      unsigned* o = reinterpret_cast<unsigned*>(p.partial) + ((long)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o[a * 4 + b] = stamp_sum[a][b];
+    }
+  }
   if (p.splitk > 1) {
     // ---- sum the K splits of this tile ------------------------------------------------------
     // Each workgroup first draws a ticket from the tile's arrival counter. All but the last to
