@@ -84,6 +84,54 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// NP consecutive 1 KiB pieces, global -> LDS without a VGPR round trip, under ONE setting of M0: lane l
+// of piece q reads 16 bytes at g[q] and lands at lds_addr + 1024 q + 16 l. The pieces are told apart
+// by the instruction's 13-bit signed immediate offset, which advances the global AND the LDS address
+// (so each source pointer is biased by minus its offset here). Why: a write to M0 waits until every
+// earlier LDS-DMA instruction of the wave has read it, ~180 cycles after issue — with M0 set (and
+// restored) around every piece a wave issues one piece per ~180 cycles, with one setting per run one
+// per ~50 (bench/l2_lds_bw.hip: 32 against 63 bytes per cycle and CU from L2). M0 is clobbered, not
+// restored: the kernels that use this have no other user of M0. Every piece counts in vmcnt.
+template <int NP>
+__device__ __forceinline__ void lds_dma_run(const void* const (&g)[NP], unsigned lds_addr) {
+  static_assert(NP == 1 || NP == 2 || NP == 4 || NP == 8, "pieces per run");
+  auto at = [&](int q, int off) { return reinterpret_cast<const char*>(g[q]) - off; };
+  if constexpr (NP == 8)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:-4096\n\tglobal_load_lds_dwordx4 %2, off offset:-3072\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:-2048\n\tglobal_load_lds_dwordx4 %4, off offset:-1024\n\t"
+                 "global_load_lds_dwordx4 %5, off\n\tglobal_load_lds_dwordx4 %6, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %7, off offset:2048\n\tglobal_load_lds_dwordx4 %8, off offset:3072"
+                 :: "s"(lds_addr + 4096), "v"(at(0, -4096)), "v"(at(1, -3072)), "v"(at(2, -2048)), "v"(at(3, -1024)),
+                    "v"(at(4, 0)), "v"(at(5, 1024)), "v"(at(6, 2048)), "v"(at(7, 3072))
+                 : "memory", "m0");
+  else if constexpr (NP == 4)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072"
+                 :: "s"(lds_addr), "v"(at(0, 0)), "v"(at(1, 1024)), "v"(at(2, 2048)), "v"(at(3, 3072)) : "memory", "m0");
+  else if constexpr (NP == 2)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024"
+                 :: "s"(lds_addr), "v"(at(0, 0)), "v"(at(1, 1024)) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(at(0, 0)) : "memory", "m0");
+}
+// any number of pieces: runs of 8, then 4, 2, 1
+template <int NP>
+__device__ __forceinline__ void lds_dma_pieces(const void* const (&g)[NP], unsigned lds_addr) {
+  if constexpr (NP == 1 || NP == 2 || NP == 4 || NP == 8) {
+    lds_dma_run<NP>(g, lds_addr);
+  } else {
+    static_assert(NP == 16, "1, 2, 4, 8 or 16 pieces");
+    const void* lo[8]; const void* hi[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { lo[q] = g[q]; hi[q] = g[8 + q]; }
+    lds_dma_run<8>(lo, lds_addr);
+    lds_dma_run<8>(hi, lds_addr + 8192);
+  }
+}
+
 __device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
 // GPT-2 "gelu_new": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
 __device__ __forceinline__ float gelu_tanh(float x) {

@@ -36,12 +36,6 @@ template <int V> struct IntA { static constexpr int value = V; };
 __device__ __forceinline__ void a8_gload16_nt(u32x4& dst, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
 }
-__device__ __forceinline__ void a8_gload_lds16(const void* gptr, unsigned lds_addr) {
-  unsigned saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-               "s_nop 0\n\ts_mov_b32 m0, %0"
-               : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
-}
 template <int N>
 __device__ __forceinline__ void a8_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
@@ -84,13 +78,13 @@ __global__ __launch_bounds__(kA8Threads, 2) void gemm_a8w8_kernel(GemmParams p) 
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   auto xdma = [&](int stage, int c) {
+    const void* src[XL];
 #pragma unroll
     for (int q = 0; q < XL; ++q) {
       const int row = RPI * (wv * XL + q) + lane / LPR;
-      const unsigned char* src = xq + (long)(row < p.M ? row : p.M - 1) * p.ldx + (((lane % LPR) ^ swz(row)) << 4) +
-                                 (long)(c0 + c) * BKE;
-      a8_gload_lds16(src, lds0 + stage * kStageBytes + (wv * XL + q) * 1024);
+      src[q] = xq + (long)(row < p.M ? row : p.M - 1) * p.ldx + (((lane % LPR) ^ swz(row)) << 4) + (long)(c0 + c) * BKE;
     }
+    lds_dma_pieces<XL>(src, lds0 + stage * kStageBytes + wv * XL * 1024);
   };
   const u32x4* wbase[NTW];
 #pragma unroll

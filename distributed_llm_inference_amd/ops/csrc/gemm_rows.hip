@@ -54,20 +54,44 @@ struct RowsCfg {
   static_assert(2 * XP + 4 * LW <= 63, "vmcnt is a 6-bit counter");
 };
 
-// 16 B per lane, global -> LDS: lane l lands at lds_addr + 16 l. M0 carries the wave-uniform LDS
-// address and is restored, since the compiler does not expect inline asm to change it.
-__device__ __forceinline__ void r2_dma16(const void* gptr, unsigned lds_addr) {
-  unsigned saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-               "s_nop 0\n\ts_mov_b32 m0, %0"
-               : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
+// NP consecutive 1 KiB pieces, global -> LDS, under ONE setting of M0 (lane l of piece q lands at
+// lds_addr + 1024 q + 16 l). The instruction's 13-bit signed immediate offset selects the piece; it
+// advances the global AND the LDS address, so the caller passes every source pointer biased by
+// minus r2_piece_off<NP>(q). A write to M0 waits until every earlier LDS-DMA instruction of the
+// wave has read it (~180 cycles after issue): with M0 set, and restored, around every piece a wave
+// issues one piece per ~180 cycles, with one setting per run one per ~50 (bench/l2_lds_bw.hip). M0
+// is not restored: nothing else in these kernels uses it.
+template <int NP> constexpr int r2_piece_off(int q) { return q * 1024 - (NP == 8 ? 4096 : 0); }
+template <int NP>
+__device__ __forceinline__ void r2_dma_run(const char* const (&g)[NP], unsigned lds_addr) {
+  static_assert(NP == 1 || NP == 2 || NP == 4 || NP == 8, "pieces per run");
+  if constexpr (NP == 8)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:-4096\n\tglobal_load_lds_dwordx4 %2, off offset:-3072\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:-2048\n\tglobal_load_lds_dwordx4 %4, off offset:-1024\n\t"
+                 "global_load_lds_dwordx4 %5, off\n\tglobal_load_lds_dwordx4 %6, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %7, off offset:2048\n\tglobal_load_lds_dwordx4 %8, off offset:3072"
+                 :: "s"(lds_addr + 4096), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7])
+                 : "memory", "m0");
+  else if constexpr (NP == 4)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:2048\n\tglobal_load_lds_dwordx4 %4, off offset:3072"
+                 :: "s"(lds_addr), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]) : "memory", "m0");
+  else if constexpr (NP == 2)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %2, off offset:1024"
+                 :: "s"(lds_addr), "v"(g[0]), "v"(g[1]) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(g[0]) : "memory", "m0");
 }
-// the same, non-temporal: the weight stream is read once and must not evict x from L2
-__device__ __forceinline__ void r2_dma16_nt(const void* gptr, unsigned lds_addr) {
-  unsigned saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\t"
-               "s_nop 0\n\ts_mov_b32 m0, %0"
-               : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
+// four weight pieces (two n-tiles x two k-steps, 4 KiB in a row), non-temporal: the weight stream is
+// read once and must not evict x from L2. g0 / g1: the n-tiles' sources, the second one passed 2048 low.
+__device__ __forceinline__ void r2_dma_w4_nt(const void* g0, const void* g1_minus_2k, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off nt\n\tglobal_load_lds_dwordx4 %1, off offset:1024 nt\n\t"
+               "global_load_lds_dwordx4 %2, off offset:2048 nt\n\tglobal_load_lds_dwordx4 %2, off offset:3072 nt"
+               :: "s"(lds_addr), "v"(g0), "v"(g1_minus_2k) : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void r2_wait_vm() {
@@ -143,7 +167,7 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     // ---------------- loader L: x rows [ROWS/4 L, +ROWS/4) and the weight blocks of n-quad L ----------------
     if (n <= 0) return;
     const int L = wave - 8;
-    const void* const dummy = p.x;                          // 16 valid, L2-hot bytes
+    const void* const dummy = p.x;                          // 4 KiB of valid, L2-hot bytes
     // one DMA instruction fills 1 KiB: 8 x rows of 128 B (rows past M re-read the last row, never
     // stored to the output), or one (n-tile, k-step) weight block
     const char* xsrc[XP];
@@ -152,23 +176,22 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     for (int q = 0; q < XP; ++q) {
       const int row = 8 * (L * XP + q) + (lane >> 3);
       const int slot = (lane & 7) ^ ((row >> 1) & 7);
-      xsrc[q] = reinterpret_cast<const char*>(p.x) + (long)min(mrow0 + row, p.M - 1) * ldxb + slot * 16 + (long)c0 * 128;
+      xsrc[q] = reinterpret_cast<const char*>(p.x) + (long)min(mrow0 + row, p.M - 1) * ldxb + slot * 16 + (long)c0 * 128
+                - r2_piece_off<XP>(q);
     }
     const u32x4* wsrc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) wsrc[j] = p.wp + ((long)((nblk * 4 + L) * 2 + j) * KT + (long)c0 * 2) * 64 + lane;
     auto xdma = [&](int stage, int c) {
+      const char* g[XP];
 #pragma unroll
-      for (int q = 0; q < XP; ++q)
-        r2_dma16(xsrc[q] + (long)c * 128, lds0 + stage * C::XStage + (L * XP + q) * 1024);
+      for (int q = 0; q < XP; ++q) g[q] = xsrc[q] + (long)c * 128;
+      r2_dma_run<XP>(g, lds0 + stage * C::XStage + L * XP * 1024);
     };
-    auto wdma = [&](int slot, int c) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          r2_dma16_nt(r2_sel(c < n, wsrc[j] + (long)(c * 2 + kk) * 64, dummy),
-                      lds0 + kR2XS * C::XStage + slot * kR2WSlot + ((L * 2 + j) * 2 + kk) * 1024);
+    auto wdma = [&](int slot, int c) {          // past the end of the split: 4 KiB of x instead (valid, L2-hot, never read back)
+      r2_dma_w4_nt(r2_sel(c < n, wsrc[0] + (long)c * 128, dummy),
+                   r2_sel(c < n, reinterpret_cast<const char*>(wsrc[1] + (long)c * 128) - 2048, dummy),
+                   lds0 + kR2XS * C::XStage + slot * kR2WSlot + L * 4096);
     };
     // Per loader a chunk is XP x pieces and 4 weight pieces. Steady state: chunk c issues X(c+2)
     // then W(c+LW); the prologue issues W(0) .. W(LW-3) and then plays iterations -2 and -1.

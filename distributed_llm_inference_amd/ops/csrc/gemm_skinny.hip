@@ -58,15 +58,6 @@ __device__ __forceinline__ void gload16(u32x4& dst, const void* p) {
 __device__ __forceinline__ void gload16_nt(u32x4& dst, const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
 }
-// 16 B per lane, global -> LDS without a VGPR round trip: lane l lands at lds_addr + 16 l. M0
-// carries the (wave-uniform) LDS address and is restored, since the compiler does not expect
-// inline asm to change it. Counts in vmcnt like any other load.
-__device__ __forceinline__ void gload_lds16(const void* gptr, unsigned lds_addr) {
-  unsigned saved;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-               "s_nop 0\n\ts_mov_b32 m0, %0"
-               : "=&s"(saved) : "s"(lds_addr), "v"(gptr) : "memory");
-}
 // `c ? a : b` on pointers without a branch: hipcc otherwise branches around the load that follows,
 // and a load that sits on one arm of a diamond can no longer be counted by hand (nor by the lint).
 __device__ __forceinline__ const void* sel_ptr(bool c, const void* a, const void* b) {
@@ -135,13 +126,13 @@ __global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmPa
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   auto xdma = [&](int stage, int c) {
+    const void* src[XL];
 #pragma unroll
     for (int q = 0; q < XL; ++q) {
       const int row = RPI * (wv * XL + q) + lane / LPR;
-      const bf16* src = p.x + (long)(row < p.M ? row : p.M - 1) * p.ldx + (((lane % LPR) ^ swz(row)) << 3) +
-                        (long)(c0 + c) * BK;
-      gload_lds16(src, lds0 + stage * kStageBytes + (wv * XL + q) * 1024);
+      src[q] = p.x + (long)(row < p.M ? row : p.M - 1) * p.ldx + (((lane % LPR) ^ swz(row)) << 3) + (long)(c0 + c) * BK;
     }
+    lds_dma_pieces<XL>(src, lds0 + stage * kStageBytes + wv * XL * 1024);
   };
   const u32x4* wbase[NTW];
 #pragma unroll
