@@ -310,7 +310,7 @@ def main():
             from distributed_llm_inference_amd.parallel.launcher import plans_for
             pl = plans_for(cfg, spec)
             plans = [p.describe() for p in pl]
-            bound = round(weak_scaling_bound(spec, pl), 3)
+            bound = round(weak_scaling_bound(spec, pl, cfg.max_batch), 3)
         except Exception:
             pass
         print(json.dumps({

@@ -79,17 +79,36 @@ def even_split(num_layers: int, num_stages: int) -> List[Tuple[int, int]]:
     return out
 
 
-# Time of final norm + lm_head + sampler relative to their share of parameters: the lm_head is one
-# large well-shaped GEMM, a decoder layer is four GEMMs plus attention, norms and the KV write.
-# Measured on MI355X, Llama-3-8B, 1024-row micro-batches: head + sampler 1.12 ms against 0.76 ms
-# per layer = 1.47 layers for 2.41 layers' worth of parameters.
-HEAD_TIME_PER_PARAM = 0.61
+# Time of final norm + lm_head + sampler relative to their share of parameters. Measured on MI355X
+# in the regime every stage of a full node runs in (bench/stage_cost.py: Llama-3-8B, micro-batches of
+# 2048 rows alternating over two HIP streams, hipGraph decode, ~150 cached tokens): a step of two
+# micro-batches costs 1.842 ms per decoder layer (4 and 8 layers: 7.37 / 14.74 ms) and 4.07 ms for the
+# head (2 or 3 layers + head: 7.76 / 9.60 ms) = 2.21 layers for 2.41 layers' worth of parameters.
+# (Single-stream kernel times say 1.5-1.7 layers: the lm_head fills every CU while a layer's thin
+# GEMMs leave CUs to the other stream, so the head weighs more once two streams share the chip. In
+# the weight-streaming regime of small batches a block costs what its parameters weigh: ~1.)
+HEAD_TIME_PER_PARAM = 0.92
 
 
-# Share of a decoder layer's time spent in its attention block (the rest is the MLP block). Measured on
-# MI355X, Llama-3-8B, 2048-row micro-batches: QKV 87 + RoPE/KV 30 + attention 264 + O 58 = 439 µs
-# against gate/up 358 + down 210 = 568 µs. (By parameters the attention block is 19 %.)
-ATTN_BLOCK_SHARE = 0.44
+# Share of a decoder layer's time spent in its attention block (the rest is the MLP block) at large
+# micro-batches, same measurement: 4 layers + one attention block 8.25 ms, one more MLP block 0.94 ms
+# on top of 4 layers = 0.88 : 0.96. By parameters (what a small, weight-streaming batch pays for) the
+# attention block of Llama-3-8B is 19 %.
+ATTN_BLOCK_SHARE = 0.48
+COMPUTE_BOUND_ROWS, WEIGHT_BOUND_ROWS = 512, 128
+
+
+def attn_block_share(spec: ModelSpec, rows: Optional[int] = None) -> float:
+    """Attention block's share of a layer's time for micro-batches of `rows` sequences: the measured
+    compute-bound share from 512 rows up (and when `rows` is not given), the parameter share up to
+    128 rows, linear in between."""
+    if rows is None or rows >= COMPUTE_BOUND_ROWS:
+        return ATTN_BLOCK_SHARE
+    by_params = spec.attn_param_count() / spec.layer_param_count()
+    if rows <= WEIGHT_BOUND_ROWS:
+        return by_params
+    f = (rows - WEIGHT_BOUND_ROWS) / (COMPUTE_BOUND_ROWS - WEIGHT_BOUND_ROWS)
+    return by_params + f * (ATTN_BLOCK_SHARE - by_params)
 
 
 def head_cost_layers(spec: ModelSpec) -> float:
@@ -97,17 +116,18 @@ def head_cost_layers(spec: ModelSpec) -> float:
     return HEAD_TIME_PER_PARAM * spec.head_param_count() / spec.layer_param_count()
 
 
-def stage_costs(spec: ModelSpec, plans: Sequence["StagePlan"]) -> List[float]:
+def stage_costs(spec: ModelSpec, plans: Sequence["StagePlan"], rows: Optional[int] = None) -> List[float]:
     """Estimated cost of every stage in decoder layers (its layers, plus the head on the last)."""
-    return [ATTN_BLOCK_SHARE * len(p.attn_layers) + (1.0 - ATTN_BLOCK_SHARE) * len(p.mlp_layers)
+    a = attn_block_share(spec, rows)
+    return [a * len(p.attn_layers) + (1.0 - a) * len(p.mlp_layers)
             + (head_cost_layers(spec) if p.has_head else 0.0) for p in plans]
 
 
-def weak_scaling_bound(spec: ModelSpec, plans: Sequence["StagePlan"]) -> float:
+def weak_scaling_bound(spec: ModelSpec, plans: Sequence["StagePlan"], rows: Optional[int] = None) -> float:
     """Upper bound on pipeline efficiency set by the partition alone: every stage waits for the
     slowest one, so N stages deliver at most mean cost / max cost of N perfectly balanced ones
-    (Llama-3-8B over 8 stages: 4,4,4,4,4,5,5,2 + head -> 33.5 / (8 x 5) = 0.84)."""
-    c = stage_costs(spec, plans)
+    (Llama-3-8B over 8 stages of whole layers: 4,4,4,5,5,4,4,2 + head -> 34.2 / (8 x 5) = 0.86)."""
+    c = stage_costs(spec, plans, rows)
     return sum(c) / (len(c) * max(c))
 
 
@@ -152,7 +172,7 @@ def balanced_split(spec: ModelSpec, num_stages: int) -> List[Tuple[int, int]]:
     return bounds
 
 
-def balanced_split_blocks(spec: ModelSpec, num_stages: int) -> List[Tuple[int, int]]:
+def balanced_split_blocks(spec: ModelSpec, num_stages: int, rows: Optional[int] = None) -> List[Tuple[int, int]]:
     """Like `balanced_split`, over attention / MLP blocks: returns half-open ranges of BLOCK indices
     (block 2 i = attention of layer i, 2 i + 1 = its MLP), minimising the heaviest stage. Exact DP."""
     U = 2 * spec.num_layers
@@ -161,7 +181,8 @@ def balanced_split_blocks(spec: ModelSpec, num_stages: int) -> List[Tuple[int, i
     if num_stages > U:
         raise ValueError(f"cannot split {U} blocks into {num_stages} stages")
     head_cost = head_cost_layers(spec)
-    cost = [ATTN_BLOCK_SHARE if u % 2 == 0 else 1.0 - ATTN_BLOCK_SHARE for u in range(U)]
+    share = attn_block_share(spec, rows)
+    cost = [share if u % 2 == 0 else 1.0 - share for u in range(U)]
     pre = [0.0]
     for c in cost:
         pre.append(pre[-1] + c)
@@ -201,15 +222,17 @@ def plans_from_blocks(num_stages: int, bounds: Sequence[Tuple[int, int]]) -> Lis
 
 
 def make_plans(spec: ModelSpec, num_stages: int, mode: str = "balanced",
-               ranges: Optional[Sequence[Tuple[int, int]]] = None, split_layers: bool = False) -> List[StagePlan]:
+               ranges: Optional[Sequence[Tuple[int, int]]] = None, split_layers: bool = False,
+               rows: Optional[int] = None) -> List[StagePlan]:
     """Stage plans for `num_stages` stages.
 
     mode: "even" | "balanced" | "explicit" (with `ranges`).  Explicit ranges must tile
     [0, num_layers) contiguously with non-empty half-open intervals. `split_layers` (balanced mode):
-    stage boundaries may fall between a layer's attention and MLP blocks.
+    stage boundaries may fall between a layer's attention and MLP blocks; `rows`: sequences per
+    micro-batch the pipeline will run (weighs those blocks: `attn_block_share`).
     """
     if mode == "balanced" and ranges is None and split_layers and num_stages > 1:
-        return plans_from_blocks(num_stages, balanced_split_blocks(spec, num_stages))
+        return plans_from_blocks(num_stages, balanced_split_blocks(spec, num_stages, rows))
     if ranges is not None:
         mode = "explicit"
     if mode == "explicit":

@@ -78,6 +78,13 @@ class ModelSpec:
         # GPT-2: c_attn, c_proj, c_fc, mlp c_proj, all with biases, two LayerNorms
         return (h * 3 * h + 3 * h) + (h * h + h) + (h * i + i) + (i * h + h) + 4 * h
 
+    def attn_param_count(self) -> int:
+        """Parameters of a layer's attention block (its norm, QKV and output projections)."""
+        h = self.hidden_size
+        if self.is_llama:
+            return h * self.qkv_size + self.q_size * h + h
+        return (h * 3 * h + 3 * h) + (h * h + h) + 2 * h
+
     def embed_param_count(self) -> int:
         n = self.vocab_size * self.hidden_size
         if self.is_gpt2:

@@ -48,7 +48,8 @@ def resolve_spec(cfg: EngineConfig) -> ModelSpec:
 
 
 def plans_for(cfg: EngineConfig, spec: ModelSpec) -> List[StagePlan]:
-    return make_plans(spec, cfg.pp_size, mode=cfg.partition, ranges=cfg.layer_ranges, split_layers=cfg.split_layers)
+    return make_plans(spec, cfg.pp_size, mode=cfg.partition, ranges=cfg.layer_ranges, split_layers=cfg.split_layers,
+                      rows=cfg.max_batch)
 
 
 def kv_blocks_for(cfg: EngineConfig) -> int:

@@ -182,9 +182,15 @@ def test_partitioner():
     assert b[0][0] == 0 and b[-1][1] == 32 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
     from distributed_llm_inference_amd.models.partition import head_cost_layers, stage_costs, weak_scaling_bound
     head = head_cost_layers(s8)
-    assert 1.3 < head < 1.7                                   # 2.4 layers' worth of parameters, ~1.5 layers of time
+    assert 2.0 < head < 2.4                                   # 2.4 layers' worth of parameters, 2.2 layers of time (bench/stage_cost.py)
     cost = [e - a + (head if i == 3 else 0) for i, (a, e) in enumerate(b)]
     assert max(cost) <= 9.0 + 1e-9 and (b[-1][1] - b[-1][0]) < 8     # the lm_head stage carries fewer layers
+    from distributed_llm_inference_amd.models.partition import attn_block_share
+    assert attn_block_share(s8) == attn_block_share(s8, 2048) == 0.48 and abs(attn_block_share(s8, 64) - 0.192) < 0.002
+    assert attn_block_share(s8, 64) < attn_block_share(s8, 256) < attn_block_share(s8, 512)
+    ps = make_plans(s8, 8, split_layers=True, rows=2048)       # the shape bench.py runs on a full node
+    assert [p.describe() for p in ps] == ["0-4", "4-8", "8-12", "12-16.5", "16.5-21", "21-25.5", "25.5-30", "30-32"]
+    assert weak_scaling_bound(s8, ps, 2048) > 0.94
     p8 = make_plans(s8, 8)
     assert stage_costs(s8, p8) == cost_of(p8, head) and max(stage_costs(s8, p8)) == 5.0
     assert abs(weak_scaling_bound(s8, p8) - (32 + head) / 40) < 1e-9 and weak_scaling_bound(s8, make_plans(s8, 1)) == 1.0
@@ -379,7 +385,7 @@ def test_templates_that_carry_their_own_bos_get_exactly_one():
 
 def test_balanced_partition_over_attention_and_mlp_blocks():
     """Stage boundaries inside layers: every block belongs to exactly one stage, the bound set by the
-    slowest stage improves (Llama-3-8B over 8 stages: 0.84 -> 0.92), and a stage that holds half a
+    slowest stage improves (Llama-3-8B over 8 stages: 0.86 -> 0.95), and a stage that holds half a
     layer needs only that half's tensors."""
     from distributed_llm_inference_amd.models.partition import (balanced_split_blocks, make_plans, plans_from_blocks,
                                                                 weak_scaling_bound)
@@ -402,7 +408,7 @@ def test_balanced_partition_over_attention_and_mlp_blocks():
         if not spec.tie_embeddings:
             assert len(names) == len(set(names))            # nothing is loaded twice
     spec = ModelSpec.from_pretrained("llama-3-8b")
-    assert weak_scaling_bound(spec, make_plans(spec, 8)) < 0.85 < 0.9 < weak_scaling_bound(spec, make_plans(spec, 8, split_layers=True))
+    assert weak_scaling_bound(spec, make_plans(spec, 8)) < 0.87 < 0.93 < weak_scaling_bound(spec, make_plans(spec, 8, split_layers=True))
     p = plans_from_blocks(2, [(0, 5), (5, 8)])
     assert [x.describe() for x in p] == ["0-2.5", "2.5-4"] and p[0].attn_layers == [0, 1, 2] and p[0].mlp_layers == [0, 1]
     assert p[1].attn_layers == [3] and p[1].mlp_layers == [2, 3]
