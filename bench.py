@@ -9,10 +9,11 @@ random-init weights.
 
 One rank per GPU; rank = pipeline stage; hidden states hop stage to stage over RCCL send/recv,
 sampled token ids hop back from the last stage to stage 0. A "step" is one decode step of EVERY
-in-flight sequence: each of the 2N micro-batches (2048 sequences each) goes once through all N
-stages — embedding, every decoder layer against the paged KV cache, final norm, lm_head,
-temperature/top-k/top-p sampling, token feedback. Per-GPU work per step is constant in N (2N
-micro-batches x L/N layers), i.e. weak scaling. A stage rotates its micro-batches over 2 HIP
+in-flight sequence: each of the micro-batches (2048 sequences each; 2 on one GPU, 2N + 2 on N > 1:
+two per stage plus two spares that cover the hops) goes once through all N stages — embedding,
+every decoder layer against the paged KV cache, final norm, lm_head, temperature/top-k/top-p
+sampling, token feedback. Per-GPU work per token is constant in N (L/N layers per stage visit),
+i.e. weak scaling. A stage rotates its micro-batches over 2 HIP
 streams, so the kernels of two micro-batches overlap on each GPU (measured on one MI355X:
 2 x 2048 rows 67.1k tok/s at 61 ms per token, 2 x 1536 65.5k at 47 ms, 2 x 1024 61.5k at 33 ms —
 pick the latency point with --batch / --micro-batches / --decode-streams). Prefill of the synthetic prompts and W warm-up
@@ -56,7 +57,7 @@ def parse():
                     help="sequences per micro-batch (default: 2048 for bf16 and fp8; 256 for fp8w, whose GEMM\n"
                          "streams at most 256 rows per pass)")
     ap.add_argument("--micro-batches", type=int, default=0,
-                    help="in-flight micro-batches (default: 2 x gpus for bf16 and fp8, 3 x gpus for fp8w)")
+                    help="in-flight micro-batches (default for bf16 and fp8: 2 on one GPU, 2 x gpus + 2 on more; 3 x gpus for fp8w)")
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--partition", default="balanced")
     ap.add_argument("--whole-layers", action="store_true", help="balanced partition over whole layers only (A/B)")
@@ -255,7 +256,11 @@ def main():
     wide = a.dtype in ("bf16", "fp8")
     a.batch = a.batch or (8 if a.cpu else (2048 if wide else 256))
     a.decode_streams = a.decode_streams or (2 if wide else 3)
-    nmb = a.micro_batches or (2 if wide else 3) * max(1, world)
+    # More than one stage: two spare micro-batches. With exactly two per stage every micro-batch is always
+    # being computed somewhere, so each hop's latency (16.8 MB of hidden state over one xGMI link, ~0.35 ms
+    # against ~7.7 ms per stage visit at 8 stages) is a bubble nobody fills: bench/pipeline_sim.py gives 0.967
+    # of the stages' capacity at 8 stages (0.90 with 1 ms hops) and 1.00 with two spares, whatever the hop.
+    nmb = a.micro_batches or ((2 if wide else 3) * max(1, world) + (2 if world > 1 and wide else 0))
     max_seq = ((a.prompt_len + a.steps + a.warmup + 2 + 31) // 32) * 32
     if not a.cpu:
         a.batch = _fit_batch(a, nmb, max_seq, max(1, world))
