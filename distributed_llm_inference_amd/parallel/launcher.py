@@ -270,6 +270,9 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
     board.register(rank, plan.layer_start, plan.layer_end)
     try:
         if world > 1:
+            if dev_kind == "cuda":
+                from .rccl import limit_p2p_channels
+                limit_p2p_channels()             # before any RCCL communicator exists (also the rccl-torch fallback's)
             init_distributed(rank, world, backend, master_port, device if dev_kind == "cuda" else None)
         ex = build_executor(cfg, spec, plan, device=device, defer_kv=True)
         settle_kv(ex, board.agree_kv_blocks(rank, kv_budget(cfg, ex, share)))

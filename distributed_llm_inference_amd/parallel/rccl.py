@@ -27,12 +27,26 @@ class RcclError(RuntimeError):
     pass
 
 
+def limit_p2p_channels():
+    """RCCL's point-to-point kernels take one workgroup per channel — 32 of them for the 16.8 MB of
+    a 2048-row hidden state with the defaults (measured on MI355X, `bench/debug/hop_grid.sh`), 132
+    registers per lane each. A receive is posted as soon as its descriptor arrives and then spins
+    until the previous stage has computed, for milliseconds: every CU it sits on cannot take a GEMM
+    workgroup meanwhile (those need the whole register file), 12 % of the chip. Four channels move
+    the same message at ~80 GB/s on one device (one: 22, two: 43), more than an xGMI link carries,
+    and keep the spinning to 4 CUs. Read by RCCL when it first initialises; an explicit setting in
+    the environment wins."""
+    os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "4")
+    os.environ.setdefault("NCCL_MIN_P2P_NCHANNELS", "1")
+
+
 def lib():
     """Loads `_comm.so` and points it at the RCCL library of this PyTorch build."""
     global _lib
     with _lock:
         if _lib is not None:
             return _lib
+        limit_p2p_channels()
         from ..ops import build as _b
         path = os.path.join(os.path.dirname(_b.__file__), "_comm.so")
         if not os.path.exists(path):
