@@ -215,12 +215,30 @@ def rccl_links_or_fallback(rank: int, world: int, job: str, device: str, slot: i
     ]
     log = get_logger()
     last = None
+    bringup_timeout_s = float(os.environ.get("DLIA_TRANSPORT_BRINGUP_TIMEOUT_S", "180"))
     for i, (name, make) in enumerate(attempts):
         links, err = None, None
-        try:
-            links = make(job if i == 0 else f"{job}_t{i}")       # fresh ring names per attempt
-        except BaseException as e:                                # noqa: BLE001 - reported below, agreed on by all ranks
-            err = e
+        # Communicator creation blocks inside the library until every peer has joined; a fabric that
+        # never lets them meet would hang the rank for good. The attempt therefore runs on a helper
+        # thread with a deadline: a rank that gives up reports failure like any other, all ranks move
+        # on to the next transport together, and the stuck thread is left behind (daemon).
+        box = {}
+
+        def attempt(make=make, j=job if i == 0 else f"{job}_t{i}"):      # fresh ring names per attempt
+            try:
+                if device.startswith("cuda"):
+                    torch.cuda.set_device(torch.device(device))          # HIP's current device is per thread
+                box["links"] = make(j)
+            except BaseException as e:                            # noqa: BLE001 - reported below, agreed on by all ranks
+                box["err"] = e
+
+        th = threading.Thread(target=attempt, name=f"dlia-bringup-{name}", daemon=True)
+        th.start()
+        th.join(bringup_timeout_s if name != "gloo" else None)
+        if th.is_alive():
+            err = TimeoutError(f"{name} links did not come up within {bringup_timeout_s:.0f} s")
+        else:
+            links, err = box.get("links"), box.get("err")
         ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:

@@ -122,6 +122,9 @@ def fallback_rank_main(rank: int, world: int, port: int, tmpdir: str):
     def native(r, w, job, device, ctrl_slot_bytes=0, warmup_timeout_s=0):
         seen["jobs"].append(job)
         if r == 1:
+            if os.environ.get("DLIA_TEST_FALLBACK_HANG") == "1":      # a communicator creation that never returns
+                import time
+                time.sleep(3600)
             raise RuntimeError("ncclCommInitRank: unhandled system error (test)")
         return FakeLinks(r, w)
 

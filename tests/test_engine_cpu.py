@@ -311,14 +311,20 @@ def test_descriptor_ring_slots_are_sized_from_the_configuration():
     assert len(worst.to_bytes()) <= ctrl_slot_bytes(c)
 
 
-def test_ranks_agree_on_a_fallback_transport_when_one_of_them_cannot_bring_the_first_up(tmp_path):
+@pytest.mark.parametrize("hang", [False, True])
+def test_ranks_agree_on_a_fallback_transport_when_one_of_them_cannot_bring_the_first_up(tmp_path, hang, monkeypatch):
     """Native RCCL hops -> torch.distributed NCCL groups -> host-staged gloo: an attempt that fails on
     ANY rank is abandoned by ALL ranks (its links aborted and closed where they came up), so a
-    pipeline never ends up with two ends of a hop on different transports."""
+    pipeline never ends up with two ends of a hop on different transports. `hang`: the failing rank's
+    communicator creation never returns instead of raising; the bring-up deadline turns that into a
+    failure like any other."""
     import json
     import torch.multiprocessing as mp
     from helpers import fallback_rank_main
-    port = 29000 + (os.getpid() % 1000)
+    port = 29000 + (os.getpid() % 1000) + (500 if hang else 0)
+    if hang:
+        monkeypatch.setenv("DLIA_TEST_FALLBACK_HANG", "1")
+        monkeypatch.setenv("DLIA_TRANSPORT_BRINGUP_TIMEOUT_S", "2")
     mp.spawn(fallback_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     assert [g["transport"] for g in got] == ["gloo", "gloo"]
