@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--isolate", action="store_true", help="stage processes as children of this one (what `serve` does on GPUs)")
     ap.add_argument("--max-seq-len", type=int, default=0)
+    ap.add_argument("--prefill-chunk", type=int, default=0, help="EngineConfig.prefill_chunk: tokens per prefill step")
     ap.add_argument("--closed-loop", type=int, default=0, metavar="CLIENTS",
                     help="CLIENTS requests outstanding at any time, each completion submits the next (default: all at t = 0)")
     ap.add_argument("--admit-fill", type=float, default=None, help="EngineConfig.admit_fill_fraction")
@@ -44,7 +45,7 @@ def main():
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="closed loop: spread the first CLIENTS arrivals over this long")
     a = ap.parse_args()
     cfg = EngineConfig(model=a.model, pp_size=a.pp_size, max_batch=a.batch, num_micro_batches=a.micro_batches,
-                       max_seq_len=a.max_seq_len or ((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=2048, isolate=a.isolate, dtype=a.dtype, kv_dtype=a.kv_dtype,
+                       max_seq_len=a.max_seq_len or ((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=a.prefill_chunk or EngineConfig().prefill_chunk, isolate=a.isolate, dtype=a.dtype, kv_dtype=a.kv_dtype,
                        device="cpu" if a.cpu else "auto", backend="torch" if a.cpu else "auto",
                        transport="loopback" if a.cpu else "auto")
     if a.admit_fill is not None:

@@ -36,7 +36,10 @@ class EngineConfig:
     max_batch: int = 64                    # sequences per micro-batch
     num_micro_batches: int = 0             # in-flight micro-batches (0 -> pp_size, >= 1)
     max_seq_len: int = 2048
-    prefill_chunk: int = 2048              # max new tokens per prefill step
+    # max new tokens per prefill step. 4096 rows fill the 256-CU chip with whole rounds of 256 x 256 GEMM
+    # tiles (Llama-3-8B gate/up: 1792 tiles = 7.0 rounds; 2048 rows: 3.5): prefill alone 91 k tok/s against
+    # 82 k, a 4096-request serving run 363 against 339 requests/s with lower TTFT and TPOT (one MI355X)
+    prefill_chunk: int = 4096
     kv_blocks: int = 0                     # KV blocks per stage (0 -> sized from free device memory, see kv_mem_fraction)
     kv_mem_fraction: float = 0.85          # share of the memory left after weights and workspaces that the KV cache takes
     use_graphs: bool = True                # hipGraph-captured decode
