@@ -9,6 +9,13 @@
 // (runtime/head.py::head_main), which answers through the same queue so that results leave in
 // submission order and the result ring keeps its single producer.
 //
+// The same loop serves a stage behind stage 0 of a multi-stage pipeline (dlia_stage_*): a replay
+// descriptor from the previous stage's ring -> block-table growth -> receive of the hidden states
+// into the graph's input buffer (the hop's own stream; the micro-batch's stream waits for it) ->
+// hipGraphLaunch -> descriptor on to the next stage's ring -> send of the output buffer (the last
+// stage: the sampled ids back to stage 0). The hop is reached through a table of three functions,
+// so the RCCL hop between processes (rccl_edge.cpp) and the in-process hop (local_edge.cpp) both fit.
+//
 // The reference's counterpart is the Flask request handler around model.forward
 // (Worker1.py:208-245; orchestration.py:109-196).
 #include <hip/hip_runtime_api.h>
@@ -39,11 +46,22 @@ static_assert(sizeof(DescHead) == 40, "descriptor header layout");
 typedef int (*ring_get_fn)(void*, void*, uint32_t, int);
 typedef int (*ring_put_fn)(void*, const void*, uint32_t, int);
 
+typedef int (*edge_send_fn)(void*, const void*, size_t, void*);
+typedef int (*edge_recv_fn)(void*, void*, size_t, void*, void*);
+typedef int (*edge_wait_fn)(void*, int, void*);
+struct EdgeRef {                                 // one end of a hop: the receiving end of `in`, the sending end of `out`
+  void* h = nullptr; edge_send_fn send = nullptr; edge_recv_fn recv = nullptr; edge_wait_fn wait = nullptr;
+};
+
 struct Mb {
   hipGraphExec_t exec = nullptr;
   hipStream_t stream = nullptr;
   const int32_t* tokens = nullptr;               // device: the graph's sampled ids
   int rows = 0;
+  // a stage behind stage 0: the graph's input (hidden states) and output (hidden states, or the ids on the last stage)
+  void* in_ptr = nullptr; size_t in_bytes = 0;
+  const void* out_ptr = nullptr; size_t out_bytes = 0;
+  int send_tok = -1;                             // completion of the latest send out of out_ptr
   int32_t* host[kSlots] = {};
   hipEvent_t ev[kSlots] = {};
   int next = 0;
@@ -62,6 +80,7 @@ struct Loop {
   int32_t* grow_stage = nullptr; int grow_pos = 0;                                  // pinned staging for growth values
   std::vector<uint8_t> out;
   uint64_t native_steps = 0, handed_up = 0;
+  EdgeRef ein, eout;                             // stage loop only: the hop in, the hop out
   char err[256] = {0};
 };
 
@@ -160,9 +179,17 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
   Loop* l = static_cast<Loop*>(h);
   if (hipSetDevice(l->device) != hipSuccess) return -1;
   auto t0 = std::chrono::steady_clock::now();
-  int idle_spins = 0;
+  const auto t_enter = t0;
+  int idle_spins = 0, since_check = 0;
   for (;;) {
     if (drain(l, res_ring) != 0) return -1;
+    // back to the caller every idle_ms also under load, so that its heartbeat stays fresh while steps
+    // never stop coming (queued results stay queued here and leave on the next call)
+    if (idle_ms >= 0 && ++since_check >= 64) {
+      since_check = 0;
+      if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_enter).count() >= idle_ms)
+        return 0;
+    }
     const int n = l->rget(cin_ring, msg_out, cap, 0);
     if (n == -3) return -2;                                   // closed and drained
     if (n == -2) { snprintf(l->err, sizeof(l->err), "descriptor larger than the message buffer"); return -1; }
@@ -205,6 +232,105 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
     HIPCHK(l, hipMemcpyAsync(m.host[s], m.tokens, (size_t)m.rows * 4, hipMemcpyDeviceToHost, m.stream));
     HIPCHK(l, hipEventRecord(m.ev[s], m.stream));
     l->pending.push_back(Pending{d->step_id, m.rows, m.host[s], m.ev[s]});
+    l->native_steps++;
+  }
+}
+
+// ---- a stage behind stage 0 ------------------------------------------------------------------------
+// The hops of this stage: `in` = the receiving end of the hop from the previous stage, `out` = the
+// sending end of the hop to the next stage (on the last stage: of the token feedback hop to stage 0).
+int dlia_stage_set_edges(void* h, void* in_h, void* in_recv, void* in_wait, void* out_h, void* out_send, void* out_wait) {
+  Loop* l = static_cast<Loop*>(h);
+  l->ein.h = in_h; l->ein.recv = (edge_recv_fn)in_recv; l->ein.wait = (edge_wait_fn)in_wait;
+  l->eout.h = out_h; l->eout.send = (edge_send_fn)out_send; l->eout.wait = (edge_wait_fn)out_wait;
+  return 0;
+}
+
+// Registers the captured decode step of micro-batch `mb` on this stage: graph, stream, its static
+// input buffer (where the receive lands) and output buffer (what is sent on). exec == null unregisters.
+int dlia_stage_set_mb(void* h, int mb, void* exec, void* stream, void* in_ptr, size_t in_bytes, const void* out_ptr,
+                      size_t out_bytes, int rows) {
+  Loop* l = static_cast<Loop*>(h);
+  if (mb < 0 || mb >= (int)l->mbs.size()) { snprintf(l->err, sizeof(l->err), "micro-batch %d out of range", mb); return -1; }
+  Mb& m = l->mbs[mb];
+  m.exec = (hipGraphExec_t)exec; m.stream = (hipStream_t)stream; m.rows = rows;
+  m.in_ptr = in_ptr; m.in_bytes = in_bytes; m.out_ptr = out_ptr; m.out_bytes = out_bytes;
+  return 0;
+}
+
+// Before control goes back to the Python loop: the micro-batch streams wait for the sends this loop
+// issued out of their output buffers, so that whatever runs on them next may overwrite those.
+static int stage_flush(Loop* l) {
+  for (Mb& m : l->mbs)
+    if (m.send_tok >= 0 && m.stream != nullptr) {
+      if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) { snprintf(l->err, sizeof(l->err), "hop: wait for a send failed"); return -1; }
+      m.send_tok = -1;
+    }
+  return 0;
+}
+
+// Serves the previous stage's descriptor ring. Returns like dlia_replay_serve: 1 = a message the
+// Python loop has to handle (in msg_out / *len), 0 = `idle_ms` passed, -2 = ring closed, -1 = error.
+// `next_ring` is null on the last stage.
+int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, uint32_t cap, uint32_t* len, int idle_ms) {
+  Loop* l = static_cast<Loop*>(h);
+  if (hipSetDevice(l->device) != hipSuccess) return -1;
+  if (!l->ein.h || !l->eout.h) { snprintf(l->err, sizeof(l->err), "stage loop without hops"); return -1; }
+  const auto t_enter = std::chrono::steady_clock::now();
+  int idle_spins = 0, since_check = 0;
+  for (;;) {
+    if (idle_ms >= 0 && ++since_check >= 64) {
+      since_check = 0;
+      if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_enter).count() >= idle_ms) {
+        return stage_flush(l) != 0 ? -1 : 0;
+      }
+    }
+    const int n = l->rget(prev_ring, msg_out, cap, 0);
+    if (n == -3) return -2;
+    if (n == -2) { snprintf(l->err, sizeof(l->err), "descriptor larger than the message buffer"); return -1; }
+    if (n < 0) {
+      if (++idle_spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else std::this_thread::yield();
+      continue;
+    }
+    idle_spins = 0;
+    const DescHead* d = static_cast<const DescHead*>(msg_out);
+    bool native = (size_t)n >= sizeof(DescHead) && d->magic == kDescMagic && d->kind == kKindStep &&
+                  (d->flags & kFlagCompact) && (d->flags & kFlagReplay) && d->mb >= 0 && d->mb < (int)l->mbs.size() &&
+                  d->ngrow >= 0 && d->ngrow <= kMaxGrow && (size_t)n >= sizeof(DescHead) + (size_t)d->ngrow * 12;
+    if (native) {
+      const Mb& m = l->mbs[d->mb];
+      native = m.exec != nullptr && m.rows == d->rows && m.in_ptr != nullptr && (d->ngrow == 0 || l->table != nullptr);
+    }
+    if (!native) {
+      if (stage_flush(l) != 0) return -1;
+      *len = (uint32_t)n;
+      l->handed_up++;
+      return 1;
+    }
+    Mb& m = l->mbs[d->mb];
+    const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
+    for (int i = 0; i < d->ngrow; ++i) {
+      const int slot = g[i], pos = g[d->ngrow + i], blk = g[2 * d->ngrow + i];
+      if (slot < 0 || slot >= l->table_rows || pos < 0 || pos >= l->max_blocks || blk < 0 || blk >= l->num_blocks) continue;
+      int32_t* src = l->grow_stage + (l->grow_pos++ & 4095);
+      *src = blk;
+      HIPCHK(l, hipMemcpyAsync(l->table + (size_t)slot * l->max_blocks + pos, src, 4, hipMemcpyHostToDevice, m.stream));
+    }
+    // the receive overwrites the input buffer: after its previous reader (the stream's earlier work)
+    const int rtok = l->ein.recv(l->ein.h, m.in_ptr, m.in_bytes, m.stream, nullptr);
+    if (rtok < 0 || l->ein.wait(l->ein.h, rtok, m.stream) != 0) { snprintf(l->err, sizeof(l->err), "hop: receive failed"); return -1; }
+    if (m.send_tok >= 0) {                                    // the graph overwrites the output buffer: after its last send
+      if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) { snprintf(l->err, sizeof(l->err), "hop: wait for a send failed"); return -1; }
+      m.send_tok = -1;
+    }
+    HIPCHK(l, hipGraphLaunch(m.exec, m.stream));
+    if (next_ring != nullptr && l->rput(next_ring, msg_out, (uint32_t)n, 5000) != 0) {   // descriptor first: the next stage posts its receive
+      snprintf(l->err, sizeof(l->err), "next stage's descriptor ring: put failed");
+      return -1;
+    }
+    m.send_tok = l->eout.send(l->eout.h, m.out_ptr, m.out_bytes, m.stream);
+    if (m.send_tok < 0) { snprintf(l->err, sizeof(l->err), "hop: send failed"); return -1; }
     l->native_steps++;
   }
 }

@@ -134,8 +134,12 @@ class LocalPipeline:
         self.plans = plans_for(cfg, self.spec)
         self.job = f"dlia_{os.getpid()}_{uuid.uuid4().hex[:8]}"
         self.board = StatusBoard(self.job + "_b", create=True, num_stages=cfg.pp_size)
-        links = make_loopback_links(cfg.pp_size)
         exs = executors or [build_executor(cfg, self.spec, p, defer_kv=True) for p in self.plans]
+        dev = getattr(exs[0], "device", None)
+        on_gpu = dev is not None and torch.device(dev).type == "cuda" and hasattr(exs[0], "decode_step")
+        act_bytes = 2 * self.spec.hidden_size * max(cfg.prefill_chunk, cfg.max_batch)
+        links = make_loopback_links(cfg.pp_size, device=dev if on_gpu else None, max_bytes=act_bytes,
+                                    fb_bytes=4 * max(cfg.max_batch, 64), job=self.job, ctrl_slot_bytes=ctrl_slot_bytes(cfg))
         # every stage's cache holds the same number of blocks: the smallest budget (the stages of an
         # in-process pipeline split one device between them)
         self.kv_blocks = min(kv_budget(cfg, ex, 1.0 / len(exs)) for ex in exs)
@@ -171,6 +175,9 @@ class LocalPipeline:
         for t in self.threads:
             t.join(5.0)
         self.runtimes[0].dump_trace()
+        if not any(t.is_alive() for t in self.threads):
+            for rt in self.runtimes:                  # device hops and rings of an in-process GPU pipeline
+                rt.links.close()
         self.board.close()
 
 

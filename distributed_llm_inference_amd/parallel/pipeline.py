@@ -316,19 +316,78 @@ class StageRuntime:
         self.links.abort()
 
 
+def _native_stage_loop_for(runtime: StageRuntime):
+    """The native loop of a stage behind stage 0 (`runtime/replay.py::NativeStageLoop`), when the stage
+    runs captured decode graphs on a GPU, its descriptors travel over shared-memory rings and its
+    hops have a native end: in-process device hops by default, RCCL hops with DLIA_NATIVE_STAGE_LOOP=1
+    (that combination cannot be exercised on a one-GPU box). DLIA_NATIVE_LOOP=0 turns it off."""
+    if os.environ.get("DLIA_NATIVE_LOOP", "1") == "0":
+        return None
+    L, ex = runtime.links, runtime.ex
+    edge_out = L.fb_data if L.is_last else L.next_data
+    if not (runtime.on_gpu and L.num_stages > 1 and not L.is_first and hasattr(ex, "decode_step") and getattr(ex, "use_graphs", False)
+            and not runtime.debug_top5 and runtime.tracer is None and not runtime.fault.rules
+            and hasattr(L.prev_ctrl, "ring") and (L.next_ctrl is None or hasattr(L.next_ctrl, "ring"))
+            and hasattr(L.prev_data, "native_ends") and hasattr(edge_out, "native_ends")):
+        return None
+    if type(L.prev_data).__name__ == "RcclEdge" and os.environ.get("DLIA_NATIVE_STAGE_LOOP") != "1":
+        return None
+    from ..runtime.replay import NativeStageLoop
+    dev = torch.device(runtime.device)
+    nl = NativeStageLoop(dev.index if dev.index is not None else torch.cuda.current_device(), getattr(ex, "decode_states", 1) + 64,
+                         L.prev_ctrl.ring, L.next_ctrl.ring if L.next_ctrl is not None else None, L.prev_data, edge_out)
+    nl.set_table(ex.block_table, ex.num_blocks)
+    return nl
+
+
+def _enter_native(runtime: StageRuntime):
+    """Hand the micro-batch streams over to the native loop: whatever the Python loop left pending on
+    them — the last eager step, sends out of the static output buffers — becomes a stream dependency."""
+    for mb, h in list(runtime._send_pending.items()):
+        s = runtime._decode_streams[mb % len(runtime._decode_streams)]
+        with torch.cuda.stream(s):
+            h.wait()
+    runtime._send_pending.clear()
+    if runtime._eager_done is not None:
+        for s in runtime._decode_streams:
+            s.wait_event(runtime._eager_done)
+
+
 def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s: float = 30.0) -> int:
     """Blocking loop of a non-zero stage: descriptors in, steps out, until SHUTDOWN.
-    Returns the number of steps executed. Errors are recorded on the status board and re-raised."""
+    Returns the number of steps executed. Errors are recorded on the status board and re-raised.
+    Replay steps of captured micro-batches are served by the native loop where there is one
+    (`_native_stage_loop_for`); everything else — prefill chunks, recompositions, control messages —
+    runs here."""
     from .shm import ST_ERROR, ST_READY, ST_STOPPED, RingClosed
     L, board = runtime.links, runtime.board
     if board is not None:
         board.set_state(runtime.stage, ST_READY)
+    nl = None
+    counted = 0
     try:
+        nl = _native_stage_loop_for(runtime)
+        runtime.native_loop = nl
         while True:
-            try:
-                msg = L.prev_ctrl.get(timeout_s=idle_beat_s)
-            except RingClosed:
-                break
+            if nl is not None:
+                _enter_native(runtime)
+                rc, msg = nl.serve(int(idle_beat_s * 1000))
+                n = nl.stats()["native_steps"]
+                if n > counted:
+                    runtime.steps += n - counted
+                    runtime.ex.graph_replays += n - counted
+                    if board is not None:
+                        board.beat(runtime.stage, n - counted, 0, 0)
+                    counted = n
+                if rc == -2:
+                    break
+                if rc == 0:
+                    msg = None
+            else:
+                try:
+                    msg = L.prev_ctrl.get(timeout_s=idle_beat_s)
+                except RingClosed:
+                    break
             if msg is None:
                 if board is not None:
                     board.beat(runtime.stage)          # idle heartbeat
@@ -339,6 +398,12 @@ def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s:
                     L.next_ctrl.put(msg)
                 break
             runtime.execute(desc)
+            if nl is not None and desc.kind == KIND_STEP and runtime._graph_decode(desc) and not desc.replay:
+                # (re)register the micro-batch's captured step: graph, stream, static input and output
+                st = runtime.ex._mb_state(desc.micro_batch, desc.num_seqs)
+                if st.graph is not None:
+                    nl.set_mb(desc.micro_batch, st.graph.raw_cuda_graph_exec(), runtime._stream_of(desc).cuda_stream,
+                              st.hidden_in, st.tokens if L.is_last else st.hidden_out, desc.num_seqs)
     except BaseException as e:
         if board is not None:
             board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
@@ -351,6 +416,9 @@ def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s:
             runtime.dump_trace()
         except Exception:
             pass
+        if nl is not None:
+            runtime.native_stats = nl.stats()
+            nl.close()
     if board is not None:
         board.set_state(runtime.stage, ST_STOPPED)
     return runtime.steps

@@ -178,6 +178,11 @@ class RcclEdge(Edge):
         _check(self.L.dlia_edge_sendrecv_on(self.h, src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size(),
                                             _stream_ptr(self.device)), f"sendrecv on {self.name}")
 
+    def native_ends(self):
+        """(handle, send, recv, wait for a send, wait for a receive) for the native stage loop."""
+        f = lambda name: C.cast(getattr(self.L, name), C.c_void_p)
+        return self.h, f("dlia_edge_send"), f("dlia_edge_recv"), f("dlia_edge_wait"), f("dlia_edge_wait")
+
     # ---- lifecycle ---------------------------------------------------------------------------
     def stats(self):
         out = (C.c_uint64 * 3)()

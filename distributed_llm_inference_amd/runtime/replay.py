@@ -29,6 +29,9 @@ def _lib():
             "dlia_replay_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
             "dlia_replay_flush": (ci, [vp, vp, ci]),
             "dlia_replay_destroy": (None, [vp]),
+            "dlia_stage_set_edges": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+            "dlia_stage_set_mb": (ci, [vp, ci, vp, vp, vp, C.c_size_t, vp, C.c_size_t, ci]),
+            "dlia_stage_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -80,6 +83,64 @@ class NativeReplay:
 
     def flush(self, timeout_s: float = 30.0) -> bool:
         return self._check(self.L.dlia_replay_flush(self.h, self.res._h, int(timeout_s * 1000)), "flush") == 0
+
+    def stats(self):
+        out = (C.c_uint64 * 2)()
+        self.L.dlia_replay_stats(self.h, out)
+        return {"native_steps": int(out[0]), "handed_to_python": int(out[1])}
+
+    def close(self):
+        if self.h:
+            self.L.dlia_replay_destroy(self.h)
+            self.h = None
+
+
+class NativeStageLoop:
+    """The native loop of a stage behind stage 0: replay descriptors from the previous stage's ring
+    -> receive -> hipGraphLaunch -> descriptor on -> send, without entering Python. `prev_ring` /
+    `next_ring`: `ShmRing`s (`next_ring` None on the last stage); `edge_in` / `edge_out`: hop objects
+    with `native_ends()` (`RcclEdge`, `LocalDeviceEdge`) — on the last stage `edge_out` is the token
+    feedback hop."""
+
+    def __init__(self, device_index: int, max_mbs: int, prev_ring, next_ring, edge_in, edge_out):
+        from ..utils import native
+        self.L = _lib()
+        rt = native.lib()
+        self.prev_ring, self.next_ring = prev_ring, next_ring
+        self.h = self.L.dlia_replay_create(device_index, max_mbs, C.cast(rt.dlia_ring_get, C.c_void_p),
+                                           C.cast(rt.dlia_ring_put, C.c_void_p))
+        if not self.h:
+            raise NativeReplayError("cannot create the native stage loop")
+        ih, _, irecv, _, iwait = edge_in.native_ends()
+        oh, osend, _, owait, _ = edge_out.native_ends()
+        self.L.dlia_stage_set_edges(self.h, ih, irecv, iwait, oh, osend, owait)
+        self._keep = (edge_in, edge_out)
+        self._buf = C.create_string_buffer(prev_ring.slot_bytes)
+        self._len = C.c_uint32(0)
+
+    def _check(self, rc: int, what: str) -> int:
+        if rc == -1:
+            raise NativeReplayError(f"{what}: {self.L.dlia_replay_error(self.h).decode(errors='replace')}")
+        return rc
+
+    def set_table(self, table, num_blocks: int):
+        self._check(self.L.dlia_replay_set_table(self.h, table.data_ptr(), table.shape[0], table.shape[1], num_blocks), "set_table")
+
+    def set_mb(self, mb: int, graph_exec: int, stream: int, inp, out, rows: int):
+        """`inp` / `out`: the graph's static input and output tensors."""
+        self._check(self.L.dlia_stage_set_mb(self.h, mb, C.c_void_p(graph_exec), C.c_void_p(stream), C.c_void_p(inp.data_ptr()),
+                                             inp.numel() * inp.element_size(), C.c_void_p(out.data_ptr()),
+                                             out.numel() * out.element_size(), rows), "set_mb")
+
+    def clear_mb(self, mb: int):
+        self.L.dlia_stage_set_mb(self.h, mb, None, None, None, 0, None, 0, 0)
+
+    def serve(self, idle_ms: int) -> Tuple[int, Optional[bytes]]:
+        """(1, message for Python) | (0, None) after `idle_ms` | (-2, None) ring closed."""
+        rc = self._check(self.L.dlia_stage_serve(self.h, self.prev_ring._h, self.next_ring._h if self.next_ring is not None else None,
+                                                 self._buf, self.prev_ring.slot_bytes, C.byref(self._len), idle_ms),
+                         "native stage loop")
+        return rc, (self._buf.raw[:self._len.value] if rc == 1 else None)
 
     def stats(self):
         out = (C.c_uint64 * 2)()

@@ -391,3 +391,36 @@ def test_single_stage_process_serves_replay_steps_natively(tmp_path, monkeypatch
     stats.unlink()
     again, _ = run_isolated(cfg(max_seq_len=256, isolate=True))
     assert again == want and not stats.exists()
+
+
+def test_stages_behind_stage_0_serve_replay_steps_natively(monkeypatch):
+    """An in-process multi-stage pipeline on the GPU runs its hops over native device hops and its
+    descriptors over shared-memory rings, and every stage behind stage 0 serves steady-state decode
+    steps in C++ (ring -> block-table growth -> receive -> hipGraphLaunch -> descriptor on -> send;
+    the last stage sends the ids back to stage 0). Same tokens as one stage and as the Python stage
+    loop; prompts long enough to cross block boundaries while decoding, more requests than rows
+    (recompositions hand control to Python and back)."""
+    ps = [p * 3 for p in prompts(20, seed=23)]
+    want, _ = run(cfg(max_seq_len=256), ps, greedy(40))
+
+    def run_pp(pp):
+        pipe = LocalPipeline(cfg(pp_size=pp, num_micro_batches=pp + 1, max_seq_len=256))
+        try:
+            assert all(l.links.transport == "local-device" for l in pipe.runtimes)
+            reqs = [pipe.engine.submit(p, greedy(40)) for p in ps]
+            outs = [r.wait(300).output for r in reqs]
+            pipe.engine.wait_idle()
+            snap = pipe.engine.snapshot()
+        finally:
+            pipe.close()
+        return outs, snap, [getattr(rt, "native_stats", None) for rt in pipe.runtimes[1:]]
+
+    for pp in (2, 3, 4):
+        got, snap, stats = run_pp(pp)
+        assert got == want and snap["fatal"] is None and snap["failed"] == 0, pp
+        for st in stats:
+            # (64-token prefill chunks of 100-200-token prompts: a third of all descriptors are Python's)
+            assert st is not None and st["native_steps"] > 2 * st["handed_to_python"] > 0, (pp, stats)
+    monkeypatch.setenv("DLIA_NATIVE_LOOP", "0")                       # the Python stage loop over the same hops
+    got, snap, stats = run_pp(3)
+    assert got == want and snap["fatal"] is None and stats == [None, None]
