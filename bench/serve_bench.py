@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"])
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--transport", default="auto", help="EngineConfig.transport (loopback: all stages in this process, sharing the GPU)")
     ap.add_argument("--isolate", action="store_true", help="stage processes as children of this one (what `serve` does on GPUs)")
     ap.add_argument("--max-seq-len", type=int, default=0)
     ap.add_argument("--prefill-chunk", type=int, default=0, help="EngineConfig.prefill_chunk: tokens per prefill step")
@@ -47,7 +48,7 @@ def main():
     cfg = EngineConfig(model=a.model, pp_size=a.pp_size, max_batch=a.batch, num_micro_batches=a.micro_batches,
                        max_seq_len=a.max_seq_len or ((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=a.prefill_chunk or EngineConfig().prefill_chunk, isolate=a.isolate, dtype=a.dtype, kv_dtype=a.kv_dtype,
                        device="cpu" if a.cpu else "auto", backend="torch" if a.cpu else "auto",
-                       transport="loopback" if a.cpu else "auto")
+                       transport="loopback" if a.cpu else a.transport)
     if a.admit_fill is not None:
         cfg.admit_fill_fraction = a.admit_fill
     if a.inflight is not None:
