@@ -49,8 +49,10 @@ typedef int (*ring_put_fn)(void*, const void*, uint32_t, int);
 typedef int (*edge_send_fn)(void*, const void*, size_t, void*);
 typedef int (*edge_recv_fn)(void*, void*, size_t, void*, void*);
 typedef int (*edge_wait_fn)(void*, int, void*);
+typedef const char* (*edge_err_fn)();
 struct EdgeRef {                                 // one end of a hop: the receiving end of `in`, the sending end of `out`
   void* h = nullptr; edge_send_fn send = nullptr; edge_recv_fn recv = nullptr; edge_wait_fn wait = nullptr;
+  edge_err_fn err = nullptr;                     // the hop library's last error text (this thread's)
 };
 
 struct Mb {
@@ -239,11 +241,17 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
 // ---- a stage behind stage 0 ------------------------------------------------------------------------
 // The hops of this stage: `in` = the receiving end of the hop from the previous stage, `out` = the
 // sending end of the hop to the next stage (on the last stage: of the token feedback hop to stage 0).
-int dlia_stage_set_edges(void* h, void* in_h, void* in_recv, void* in_wait, void* out_h, void* out_send, void* out_wait) {
+int dlia_stage_set_edges(void* h, void* in_h, void* in_recv, void* in_wait, void* in_err, void* out_h, void* out_send,
+                         void* out_wait, void* out_err) {
   Loop* l = static_cast<Loop*>(h);
-  l->ein.h = in_h; l->ein.recv = (edge_recv_fn)in_recv; l->ein.wait = (edge_wait_fn)in_wait;
-  l->eout.h = out_h; l->eout.send = (edge_send_fn)out_send; l->eout.wait = (edge_wait_fn)out_wait;
+  l->ein.h = in_h; l->ein.recv = (edge_recv_fn)in_recv; l->ein.wait = (edge_wait_fn)in_wait; l->ein.err = (edge_err_fn)in_err;
+  l->eout.h = out_h; l->eout.send = (edge_send_fn)out_send; l->eout.wait = (edge_wait_fn)out_wait; l->eout.err = (edge_err_fn)out_err;
   return 0;
+}
+
+static int hop_fail(Loop* l, const char* what, const EdgeRef& e) {
+  snprintf(l->err, sizeof(l->err), "hop: %s: %s", what, e.err ? e.err() : "?");
+  return -1;
 }
 
 // Registers the captured decode step of micro-batch `mb` on this stage: graph, stream, its static
@@ -263,7 +271,7 @@ int dlia_stage_set_mb(void* h, int mb, void* exec, void* stream, void* in_ptr, s
 static int stage_flush(Loop* l) {
   for (Mb& m : l->mbs)
     if (m.send_tok >= 0 && m.stream != nullptr) {
-      if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) { snprintf(l->err, sizeof(l->err), "hop: wait for a send failed"); return -1; }
+      if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) return hop_fail(l, "wait for a send", l->eout);
       m.send_tok = -1;
     }
   return 0;
@@ -319,9 +327,9 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
     }
     // the receive overwrites the input buffer: after its previous reader (the stream's earlier work)
     const int rtok = l->ein.recv(l->ein.h, m.in_ptr, m.in_bytes, m.stream, nullptr);
-    if (rtok < 0 || l->ein.wait(l->ein.h, rtok, m.stream) != 0) { snprintf(l->err, sizeof(l->err), "hop: receive failed"); return -1; }
+    if (rtok < 0 || l->ein.wait(l->ein.h, rtok, m.stream) != 0) return hop_fail(l, "receive", l->ein);
     if (m.send_tok >= 0) {                                    // the graph overwrites the output buffer: after its last send
-      if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) { snprintf(l->err, sizeof(l->err), "hop: wait for a send failed"); return -1; }
+      if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) return hop_fail(l, "wait for a send", l->eout);
       m.send_tok = -1;
     }
     HIPCHK(l, hipGraphLaunch(m.exec, m.stream));
@@ -330,7 +338,7 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
       return -1;
     }
     m.send_tok = l->eout.send(l->eout.h, m.out_ptr, m.out_bytes, m.stream);
-    if (m.send_tok < 0) { snprintf(l->err, sizeof(l->err), "hop: send failed"); return -1; }
+    if (m.send_tok < 0) return hop_fail(l, "send", l->eout);
     l->native_steps++;
   }
 }

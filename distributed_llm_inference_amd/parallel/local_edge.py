@@ -96,9 +96,9 @@ class LocalDeviceEdge(Edge):
         return _LocalHandle(self, tok, 1, keep=buf)
 
     def native_ends(self):
-        """(handle, send, recv, wait for a send, wait for a receive) for the native stage loop."""
+        """(handle, send, recv, wait for a send, wait for a receive, last error text) for the native stage loop."""
         f = lambda name: C.cast(getattr(self.L, name), C.c_void_p)
-        return self.h, f("dlia_ledge_send"), f("dlia_ledge_recv"), f("dlia_ledge_wait_send"), f("dlia_ledge_wait_recv")
+        return self.h, f("dlia_ledge_send"), f("dlia_ledge_recv"), f("dlia_ledge_wait_send"), f("dlia_ledge_wait_recv"), f("dlia_ledge_last_error")
 
     def abort(self):
         if not self.closed:

@@ -179,9 +179,9 @@ class RcclEdge(Edge):
                                             _stream_ptr(self.device)), f"sendrecv on {self.name}")
 
     def native_ends(self):
-        """(handle, send, recv, wait for a send, wait for a receive) for the native stage loop."""
+        """(handle, send, recv, wait for a send, wait for a receive, last error text) for the native stage loop."""
         f = lambda name: C.cast(getattr(self.L, name), C.c_void_p)
-        return self.h, f("dlia_edge_send"), f("dlia_edge_recv"), f("dlia_edge_wait"), f("dlia_edge_wait")
+        return self.h, f("dlia_edge_send"), f("dlia_edge_recv"), f("dlia_edge_wait"), f("dlia_edge_wait"), f("dlia_comm_last_error")
 
     # ---- lifecycle ---------------------------------------------------------------------------
     def stats(self):

@@ -29,7 +29,7 @@ def _lib():
             "dlia_replay_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
             "dlia_replay_flush": (ci, [vp, vp, ci]),
             "dlia_replay_destroy": (None, [vp]),
-            "dlia_stage_set_edges": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+            "dlia_stage_set_edges": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
             "dlia_stage_set_mb": (ci, [vp, ci, vp, vp, vp, C.c_size_t, vp, C.c_size_t, ci]),
             "dlia_stage_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
         }
@@ -111,9 +111,9 @@ class NativeStageLoop:
                                            C.cast(rt.dlia_ring_put, C.c_void_p))
         if not self.h:
             raise NativeReplayError("cannot create the native stage loop")
-        ih, _, irecv, _, iwait = edge_in.native_ends()
-        oh, osend, _, owait, _ = edge_out.native_ends()
-        self.L.dlia_stage_set_edges(self.h, ih, irecv, iwait, oh, osend, owait)
+        ih, _, irecv, _, iwait, ierr = edge_in.native_ends()
+        oh, osend, _, owait, _, oerr = edge_out.native_ends()
+        self.L.dlia_stage_set_edges(self.h, ih, irecv, iwait, ierr, oh, osend, owait, oerr)
         self._keep = (edge_in, edge_out)
         self._buf = C.create_string_buffer(prev_ring.slot_bytes)
         self._len = C.c_uint32(0)
