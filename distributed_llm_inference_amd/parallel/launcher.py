@@ -285,6 +285,13 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
             # (RCCL refuses two ranks on one GPU); used to rehearse a multi-stage job on a small box
             share = 1.0 / ((world + ndev - 1) // ndev)
             idx %= ndev
+            if transport != "gloo" and os.environ.get("DLIA_RCCL_DISTINCT_HOSTS") == "1":
+                # Rehearsal of the RCCL transports on a box with fewer GPUs than stages: RCCL refuses two
+                # ranks of one communicator on one device of one HOST, and tells hosts apart by NCCL_HOSTID.
+                # With a different id per rank the ranks count as different hosts and their hops go over
+                # RCCL's socket transport — the same ncclSend / ncclRecv calls, fences and streams as on a
+                # full node, minus xGMI. Read by RCCL when it first initialises.
+                os.environ["NCCL_HOSTID"] = f"dlia-rehearsal-rank-{rank}"
         elif ndev > 0 and world > ndev and transport == "gloo":
             share = 1.0 / ((world + ndev - 1) // ndev)
         device = f"cuda:{idx}"

@@ -319,8 +319,8 @@ class StageRuntime:
 def _native_stage_loop_for(runtime: StageRuntime):
     """The native loop of a stage behind stage 0 (`runtime/replay.py::NativeStageLoop`), when the stage
     runs captured decode graphs on a GPU, its descriptors travel over shared-memory rings and its
-    hops have a native end: in-process device hops by default, RCCL hops with DLIA_NATIVE_STAGE_LOOP=1
-    (that combination cannot be exercised on a one-GPU box). DLIA_NATIVE_LOOP=0 turns it off."""
+    hops have a native end (in-process device hops, RCCL hops). DLIA_NATIVE_LOOP=0 turns it off, and
+    DLIA_NATIVE_STAGE_LOOP=0 for RCCL hops only."""
     if os.environ.get("DLIA_NATIVE_LOOP", "1") == "0":
         return None
     L, ex = runtime.links, runtime.ex
@@ -330,7 +330,7 @@ def _native_stage_loop_for(runtime: StageRuntime):
             and hasattr(L.prev_ctrl, "ring") and (L.next_ctrl is None or hasattr(L.next_ctrl, "ring"))
             and hasattr(L.prev_data, "native_ends") and hasattr(edge_out, "native_ends")):
         return None
-    if type(L.prev_data).__name__ == "RcclEdge" and os.environ.get("DLIA_NATIVE_STAGE_LOOP") != "1":
+    if type(L.prev_data).__name__ == "RcclEdge" and os.environ.get("DLIA_NATIVE_STAGE_LOOP", "1") == "0":
         return None
     from ..runtime.replay import NativeStageLoop
     dev = torch.device(runtime.device)

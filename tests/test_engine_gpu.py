@@ -424,3 +424,61 @@ def test_stages_behind_stage_0_serve_replay_steps_natively(monkeypatch):
     monkeypatch.setenv("DLIA_NATIVE_LOOP", "0")                       # the Python stage loop over the same hops
     got, snap, stats = run_pp(3)
     assert got == want and snap["fatal"] is None and stats == [None, None]
+
+
+@pytest.mark.parametrize("native_loop", [False, True], ids=["python stage loop", "native stage loop"])
+@pytest.mark.parametrize("pp", [2, 4])
+def test_stage_processes_over_native_rccl_hops_give_the_single_stage_tokens(pp, native_loop, monkeypatch):
+    """Separate OS processes per stage over the NATIVE RCCL transport — per-hop communicators from
+    ids broadcast over gloo, ncclSend / ncclRecv on the hop's own stream behind event fences, token
+    feedback hop, warm-up messages — on this one GPU: RCCL tells hosts apart by NCCL_HOSTID, and with a
+    different id per rank (DLIA_RCCL_DISTINCT_HOSTS) it accepts ranks that share a device and moves
+    their messages over its socket transport. The calls, fences and streams are those of a full
+    node; only xGMI is missing. Same greedy tokens as the in-process single-stage engine, with the
+    Python stage loop and with the native one behind stage 0 (DLIA_NATIVE_STAGE_LOOP)."""
+    from distributed_llm_inference_amd.parallel.launcher import SpawnedPipeline
+    monkeypatch.setenv("DLIA_SHARE_GPU", "1")
+    monkeypatch.setenv("DLIA_RCCL_DISTINCT_HOSTS", "1")
+    monkeypatch.setenv("DLIA_NATIVE_STAGE_LOOP", "1" if native_loop else "0")
+    ps = [p * 2 for p in prompts(12, seed=9)]
+    ref, _ = run(cfg(), ps, greedy(24))
+    pipe = SpawnedPipeline(cfg(pp_size=pp, num_micro_batches=pp + 1, transport="rccl"))
+    try:
+        pipe.wait_ready(timeout=300)
+        reqs = [pipe.engine.submit(p, greedy(24)) for p in ps]
+        got = [r.wait(180).output for r in reqs]
+        snap = pipe.engine.snapshot()
+        assert snap["fatal"] is None and snap["failed"] == 0
+    finally:
+        pipe.close()
+    assert got == ref
+
+
+def test_a_stage_process_dying_behind_native_rccl_hops_is_answered_and_replaced(monkeypatch):
+    """The failure path over the transport a full node uses: stage 1 of two stage processes on native
+    RCCL hops exits at its third step. Its neighbours' transfers can never complete; the serving
+    process (no GPU context, no communicator) answers {"status": "failed"} in time, kills what is
+    left — hops aborted, nothing drained — and the next request runs on fresh stage processes."""
+    import time
+    from distributed_llm_inference_amd.parallel.launcher import make_pipeline
+    from distributed_llm_inference_amd.serving.orchestrator import EngineBackend
+    from distributed_llm_inference_amd.utils.procs import pid_alive
+    monkeypatch.setenv("DLIA_SHARE_GPU", "1")
+    monkeypatch.setenv("DLIA_RCCL_DISTINCT_HOSTS", "1")
+    pipe = make_pipeline(cfg(pp_size=2, partition="even", num_micro_batches=3, transport="rccl", fault_inject="stage1:exit@3",
+                             hop_timeout_s=5, auto_restart=True))
+    b = EngineBackend(pipe)
+    try:
+        pipe.wait_ready(timeout=300)
+        old_pids = [p.pid for p in pipe.procs]
+        t0 = time.time()
+        first = b.generate("Hello", 20, 0.0)
+        took = time.time() - t0
+        assert first["status"] == "failed" and first["error"].startswith("Error: "), first
+        assert took < 5 * 2 + 15, took
+        second = b.generate("Hello", 6, 0.0)
+        assert second["status"] == "success" and second["tokens_generated"] == 6, second
+        assert b.restarts == 1 and b.workers() == {"worker_1": "online", "worker_2": "online"}
+        assert not any(pid_alive(p) for p in old_pids)
+    finally:
+        b.close()
