@@ -64,8 +64,9 @@ def test_more_messages_than_staging_slots_with_a_lagging_receiver():
     th = threading.Thread(target=receiver)
     th.start()
     try:
+        sends = []                                        # a handle keeps its source alive until the copy out of it has run
         for i in range(n):
-            e.send(torch.full((16 * 1024,), i, device="cuda", dtype=torch.int32))
+            sends.append(e.send(torch.full((16 * 1024,), i, device="cuda", dtype=torch.int32)))
         th.join(60)
         assert not th.is_alive()
         torch.cuda.synchronize()
