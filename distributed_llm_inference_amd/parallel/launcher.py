@@ -280,20 +280,17 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
     if dev_kind == "cuda":
         idx = rank if local_rank is None else local_rank
         ndev = torch.cuda.device_count()
-        if idx >= ndev > 0 and (transport == "gloo" or os.environ.get("DLIA_SHARE_GPU") == "1"):
-            # more stages than GPUs: only the host-staged transport can share a device between ranks
-            # (RCCL refuses two ranks on one GPU); used to rehearse a multi-stage job on a small box
+        if world > ndev > 0 and (transport == "gloo" or os.environ.get("DLIA_SHARE_GPU") == "1"):
+            # more stages than GPUs: the host-staged transport can share a device between ranks, and so can
+            # the RCCL transports in rehearsal mode (below); used to rehearse a multi-stage job on a small box
             share = 1.0 / ((world + ndev - 1) // ndev)
             idx %= ndev
             if transport != "gloo" and os.environ.get("DLIA_RCCL_DISTINCT_HOSTS") == "1":
-                # Rehearsal of the RCCL transports on a box with fewer GPUs than stages: RCCL refuses two
-                # ranks of one communicator on one device of one HOST, and tells hosts apart by NCCL_HOSTID.
-                # With a different id per rank the ranks count as different hosts and their hops go over
-                # RCCL's socket transport — the same ncclSend / ncclRecv calls, fences and streams as on a
-                # full node, minus xGMI. Read by RCCL when it first initialises.
+                # RCCL refuses two ranks of one communicator on one device of one HOST, and tells hosts
+                # apart by NCCL_HOSTID. With a different id per rank the ranks count as different hosts and
+                # their hops go over RCCL's socket transport — the same ncclSend / ncclRecv calls, fences and
+                # streams as on a full node, minus xGMI. Read by RCCL when it first initialises.
                 os.environ["NCCL_HOSTID"] = f"dlia-rehearsal-rank-{rank}"
-        elif ndev > 0 and world > ndev and transport == "gloo":
-            share = 1.0 / ((world + ndev - 1) // ndev)
         device = f"cuda:{idx}"
         torch.cuda.set_device(torch.device(device))
     spec = resolve_spec(cfg)
