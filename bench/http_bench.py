@@ -122,11 +122,15 @@ def main():
         print(json.dumps(out))
     finally:
         if proc is not None:
-            os.killpg(proc.pid, signal.SIGTERM)
+            proc.send_signal(signal.SIGTERM)       # the server alone: it closes its stage processes itself
             try:
-                proc.wait(30)
+                proc.wait(60)
             except subprocess.TimeoutExpired:
-                os.killpg(proc.pid, signal.SIGKILL)
+                pass
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)    # whatever of its session is still there
+            except ProcessLookupError:
+                pass
 
 
 if __name__ == "__main__":
