@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--kv-dtype", default="bf16")
     ap.add_argument("--show-one", action="store_true", help="first print the whole JSON answer of one /generate")
     a = ap.parse_args()
+    import resource                      # one socket per client
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    if hard != resource.RLIM_INFINITY and soft < hard:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (hard, hard))
     proc = None
     url = a.url
     if a.spawn or not url:

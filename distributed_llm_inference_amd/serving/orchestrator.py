@@ -384,10 +384,23 @@ def create_asgi_app(backend):
     return app
 
 
+def raise_fd_limit():
+    """Soft limit of open files up to the hard limit: one socket per waiting client."""
+    try:
+        import resource
+        soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+        if hard == resource.RLIM_INFINITY or soft < hard:
+            want = hard if hard != resource.RLIM_INFINITY else max(soft, 1 << 16)
+            resource.setrlimit(resource.RLIMIT_NOFILE, (want, hard))
+    except (ImportError, ValueError, OSError):
+        pass
+
+
 def serve(cfg: EngineConfig):
     """Blocking: bring the pipeline (or the HTTP relay) up and serve the API on cfg.host:cfg.port."""
     from ..utils.tracing import get_logger
     log = get_logger()
+    raise_fd_limit()
     if cfg.resolved_transport() == "http" or cfg.worker_urls:
         backend = HttpRelayBackend(cfg)
         log.info("orchestrator (HTTP relay) for %s; workers: %s", backend.model_name, cfg.worker_urls)
