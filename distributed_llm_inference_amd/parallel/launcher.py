@@ -22,7 +22,7 @@ import socket
 import threading
 import time
 import uuid
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 import torch
 
@@ -34,7 +34,7 @@ from ..runtime.tokenizer import load_tokenizer
 from .pipeline import StageRuntime, stage_main
 from .shm import ST_ERROR, ST_READY, StatusBoard
 from ..utils.tracing import make_tracer
-from .transport import PipelineLinks, make_dist_links, make_loopback_links
+from .transport import make_dist_links, make_loopback_links
 
 
 def has_checkpoint(path: str) -> bool:

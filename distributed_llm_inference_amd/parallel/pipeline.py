@@ -24,11 +24,11 @@ import contextlib
 import os
 import time
 import traceback
-from typing import Callable, Dict, List, Optional
+from typing import Dict, List, Optional
 
 import torch
 
-from ..runtime.batch import KIND_BARRIER, KIND_PING, KIND_RELEASE, KIND_SHUTDOWN, KIND_STEP, StepBatch
+from ..runtime.batch import KIND_BARRIER, KIND_RELEASE, KIND_SHUTDOWN, KIND_STEP, StepBatch
 from .transport import Handle, PipelineLinks
 
 

@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import queue
 import threading
-from typing import Dict, List, Optional, Tuple
+from typing import List, Optional
 
 import torch
 

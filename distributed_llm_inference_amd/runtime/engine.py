@@ -35,7 +35,6 @@ import traceback
 from dataclasses import dataclass, field
 from typing import Deque, Dict, List, Optional
 
-import torch
 
 from ..config import EngineConfig
 from .batch import KIND_RELEASE, StepBatch, control

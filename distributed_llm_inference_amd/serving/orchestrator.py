@@ -21,7 +21,7 @@ import threading
 
 import itertools
 import time
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 
