@@ -151,6 +151,7 @@ class Engine:
         self.mbs = [_MicroBatch(i, cfg.max_batch) for i in range(cfg.num_micro_batches)]
         self.waiting: Deque[Request] = collections.deque()
         self._inbox: Deque[Request] = collections.deque()
+        self._cancel_box: Deque[Request] = collections.deque()
         self._lock = threading.Lock()
         self._wake = threading.Event()
         self._stop = False
@@ -170,7 +171,7 @@ class Engine:
         # counters for /metrics
         self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
                       "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0,
-                      "preemptions": 0, "kv_blocks_grown": 0}
+                      "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0}
         self.latencies: Deque[float] = collections.deque(maxlen=4096)     # per-token decode latencies (s)
         self.ttfts: Deque[float] = collections.deque(maxlen=1024)
 
@@ -218,6 +219,18 @@ class Engine:
         self._wake.set()
         return req
 
+    def cancel(self, req: Request):
+        """Abandon `req` (its client went away or stopped waiting): from any thread. The scheduler
+        marks it failed with error "cancelled" at its next tick; a queued request leaves the queue,
+        a running one stops receiving tokens at once and gives its row and KV blocks back at the
+        micro-batch's next recomposition (until then the row rides along as padding, like a row
+        that hit EOS). The reference has no way to stop a generation (orchestration.py:131-199
+        runs its loop to the end whoever is still listening)."""
+        if req.finished:
+            return
+        self._cancel_box.append(req)
+        self._wake.set()
+
     def submit_text(self, prompt: str, max_new_tokens: Optional[int] = None, temperature: Optional[float] = None,
                     top_k: Optional[int] = None, top_p: Optional[float] = None, seed: Optional[int] = None) -> Request:
         """Chat-format and tokenise `prompt`, clamp the token count, enqueue. The caller waits on the
@@ -259,11 +272,14 @@ class Engine:
         """Prompt in, text out, with the reference's result / error dictionaries
         (orchestration.py:211-228)."""
         start = time.time()
+        req = None
         try:
             req = self.submit_text(prompt, max_new_tokens, temperature, top_k, top_p, seed)
             req.wait(timeout or self.cfg.request_timeout_s)
             return self.text_result(req, prompt, start)
         except Exception as e:      # same envelope as the reference: HTTP 200, status "failed"
+            if req is not None:
+                self.cancel(req)    # nobody waits for it any more
             return {"error": f"Error: {e}", "status": "failed"}
 
     # ---- scheduler thread ------------------------------------------------------------------
@@ -273,6 +289,9 @@ class Engine:
                 progressed = False
                 while self._inbox:
                     self.waiting.append(self._inbox.popleft())
+                    progressed = True
+                while self._cancel_box:
+                    self._cancel(self._cancel_box.popleft())
                     progressed = True
                 n = len(self.mbs)
                 for i in range(n):
@@ -325,6 +344,23 @@ class Engine:
         for r in list(self.waiting) + list(self._inbox):
             self._fail(r, msg)
         self.waiting.clear()
+
+    def _cancel(self, req: Request):
+        if req.finished:
+            return
+        if req.state == "waiting":
+            try:
+                self.waiting.remove(req)
+            except ValueError:
+                pass
+        # a request that holds a row becomes a dead row: skipped by `_harvest`, not grown, retired
+        # (blocks released, slot freed on the stages) when its micro-batch is next recomposed
+        req.error, req.state = "cancelled", "failed"
+        req.t_done = time.perf_counter()
+        self.stats["cancelled"] += 1
+        if self.tracer is not None:
+            self.tracer.instant("scheduler", "cancel", {"rid": req.rid, "tokens": len(req.output)})
+        req._set_done()
 
     def _fail(self, req: Request, msg: str):
         req.error, req.state = msg, "failed"

@@ -72,15 +72,20 @@ class EngineBackend:
         return self.engine.generate_text(prompt, max_new_tokens=max_new_tokens, temperature=temperature,
                                          top_k=self.cfg.top_k, top_p=self.cfg.top_p)
 
-    async def agenerate(self, prompt, max_new_tokens, temperature):
+    async def agenerate(self, prompt, max_new_tokens, temperature, client_gone=None):
         """`generate` for an event loop: the coroutine is resumed by the scheduler thread's
-        completion callback, so thousands of requests can wait without a thread each."""
+        completion callback, so thousands of requests can wait without a thread each.
+        `client_gone`: optional coroutine function that returns once the client has disconnected.
+        A request whose client left, or that outlived `request_timeout_s`, or whose handler task is
+        cancelled (server shutdown) is cancelled in the engine, which frees its row and KV blocks
+        instead of decoding to `max_tokens` for nobody."""
         import asyncio
         loop = asyncio.get_running_loop()
         if self.cfg.auto_restart and self.engine.fatal:
             await loop.run_in_executor(None, self._recover)       # rebuilding stage processes blocks
         start = time.time()
         engine = self.engine
+        req = watch = None
         try:
             req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k, self.cfg.top_p)
             fut = loop.create_future()
@@ -89,10 +94,26 @@ class EngineBackend:
                 loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(None))
 
             req.add_done_callback(wake)
-            await asyncio.wait_for(fut, timeout=self.cfg.request_timeout_s)
+            waiters = {fut}
+            if client_gone is not None:
+                watch = asyncio.ensure_future(client_gone())
+                waiters.add(watch)
+            done, _ = await asyncio.wait(waiters, timeout=self.cfg.request_timeout_s, return_when=asyncio.FIRST_COMPLETED)
+            if fut not in done:
+                engine.cancel(req)
+                why = "client disconnected" if watch is not None and watch in done \
+                    else f"no result within {self.cfg.request_timeout_s:g}s"
+                return {"error": f"Error: {why}", "status": "failed"}
             return engine.text_result(req, prompt, start)
+        except asyncio.CancelledError:
+            if req is not None:
+                engine.cancel(req)
+            raise
         except Exception as e:                                      # HTTP 200 envelope, as the reference
             return {"error": f"Error: {e or type(e).__name__}", "status": "failed"}
+        finally:
+            if watch is not None and not watch.done():
+                watch.cancel()
 
     def workers(self) -> Dict[str, str]:
         """Stage s is reported as worker_{s+1}. online = ready with a fresh heartbeat; error = the
@@ -370,7 +391,10 @@ def create_asgi_app(backend):
         except (TypeError, ValueError):
             return js({"error": "max_tokens and temperature must be numbers"}, 400)
         if hasattr(b, "agenerate"):
-            return js(await b.agenerate(prompt, max_tokens, temperature))        # HTTP 200 even when status == failed
+            async def client_gone():            # the body has been read: the next message is the disconnect
+                while (await request.receive()).get("type") != "http.disconnect":
+                    pass
+            return js(await b.agenerate(prompt, max_tokens, temperature, client_gone))   # HTTP 200 even when status == failed
         from starlette.concurrency import run_in_threadpool
         return js(await run_in_threadpool(b.generate, prompt, max_tokens, temperature))
 

@@ -102,6 +102,83 @@ def test_asgi_app_serves_the_same_contract(backend):
         assert c.get("/workers").json() == {"worker_1": "not_configured"}
 
 
+def test_a_cancelled_request_stops_and_gives_its_row_and_blocks_back(backend):
+    """`Engine.cancel`: a queued request leaves the queue, a running one stops receiving tokens at once
+    and its KV blocks return to the pool at the next recomposition; the engine keeps serving."""
+    eng = backend.engine
+    before = eng.stats["cancelled"]
+    sp = SamplingParams(temperature=0.0, top_k=1, top_p=1.0, max_new_tokens=140, stop_on_eos=False)
+    running = eng.submit([5, 6, 7], sp)
+    deadline = time.time() + 60
+    while not running.output and time.time() < deadline:
+        time.sleep(0.005)
+    assert running.output
+    others = [eng.submit([9, i + 1], sp) for i in range(12)]     # more requests than rows (2 x 4): the last ones queue
+    queued = others[-1]
+    eng.cancel(queued)
+    eng.cancel(running)
+    running.wait(10)
+    queued.wait(10)
+    assert running.state == "failed" and running.error == "cancelled" and 0 < len(running.output) < 140
+    assert queued.state == "failed" and queued.error == "cancelled" and queued.output == []
+    n = len(running.output)
+    for r in others[:-1]:
+        eng.cancel(r)
+    eng.cancel(running)                                           # cancelling twice is harmless
+    assert eng.wait_idle(30)
+    assert eng.alloc.used == 0 and len(running.output) == n
+    assert eng.stats["cancelled"] - before == 13
+    assert "dlia_requests_cancelled_total" in backend.metrics()
+    assert eng.generate_text("still serving", max_new_tokens=4, temperature=0)["status"] == "success"
+
+
+def test_a_client_that_disconnects_cancels_its_request(backend):
+    """The ASGI handler watches for `http.disconnect` while the request decodes and cancels it in the
+    engine; a request that outlives `request_timeout_s` is cancelled the same way."""
+    import asyncio
+    import dataclasses
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    eng = backend.engine
+    app = create_asgi_app(backend)
+    body = json.dumps({"prompt": "tell me everything", "max_tokens": 150, "temperature": 0}).encode()
+
+    async def call(disconnect_after):
+        calls, sent = {"n": 0}, []
+
+        async def receive():
+            calls["n"] += 1
+            if calls["n"] == 1:
+                return {"type": "http.request", "body": body, "more_body": False}
+            await asyncio.sleep(disconnect_after)
+            return {"type": "http.disconnect"}
+
+        async def send(msg):
+            sent.append(msg)
+
+        scope = {"type": "http", "asgi": {"version": "3.0"}, "http_version": "1.1", "method": "POST", "scheme": "http",
+                 "path": "/generate", "raw_path": b"/generate", "query_string": b"", "root_path": "",
+                 "headers": [(b"content-type", b"application/json")], "server": ("127.0.0.1", 80), "client": ("127.0.0.1", 9)}
+        await app(scope, receive, send)
+        return json.loads(b"".join(m.get("body", b"") for m in sent if m["type"] == "http.response.body"))
+
+    before, toks = eng.stats["cancelled"], eng.stats["tokens_out"]
+    out = asyncio.run(call(0.05))
+    assert out["status"] == "failed" and "client disconnected" in out["error"]
+    assert eng.wait_idle(30) and eng.alloc.used == 0              # (the scheduler thread does the cancelling)
+    assert eng.stats["cancelled"] == before + 1
+    assert eng.stats["tokens_out"] - toks < 150
+    # the same request with a patient client runs to its end
+    assert asyncio.run(call(600))["status"] == "success"
+    # ... and with a server-side deadline shorter than the generation it is cancelled, not left decoding
+    backend.cfg = dataclasses.replace(backend.cfg, request_timeout_s=0.05)
+    try:
+        out = asyncio.run(call(600))
+    finally:
+        backend.cfg = dataclasses.replace(backend.cfg, request_timeout_s=200.0)
+    assert out["status"] == "failed" and "no result within" in out["error"]
+    assert eng.wait_idle(30) and eng.alloc.used == 0 and eng.stats["cancelled"] == before + 2
+
+
 def test_orchestrator_not_initialised():
     c = create_app(None).test_client()
     r = c.post("/generate", json={"prompt": "x"})

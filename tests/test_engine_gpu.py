@@ -298,6 +298,39 @@ def test_preemption_on_the_gpu_keeps_greedy_tokens():
     assert got == want
 
 
+def test_cancelling_rows_of_a_replaying_micro_batch_leaves_the_other_rows_tokens_unchanged():
+    """A cancelled row rides on as padding in the captured decode step until the micro-batch is
+    recomposed; its neighbours' greedy tokens are those of a run in which nobody was cancelled, its
+    blocks return to the pool, and requests queued behind it take its place."""
+    import time
+    ps = prompts(24, seed=21)
+    want, _ = run(cfg(), ps, greedy(48))
+    pipe = LocalPipeline(cfg())
+    try:
+        eng = pipe.engine
+        reqs = [eng.submit(p, greedy(48)) for p in ps]           # 16 rows: 8 requests start in the queue
+        victims = [reqs[1], reqs[6], reqs[12], reqs[23]]
+        deadline = time.time() + 60
+        while len(reqs[12].output) < 5 and time.time() < deadline:
+            time.sleep(0.001)
+        for r in victims:
+            eng.cancel(r)
+        for r in reqs:
+            r.wait(120)
+        assert eng.wait_idle(30)
+        snap = eng.snapshot()
+    finally:
+        pipe.close()
+    for i, r in enumerate(reqs):
+        if r in victims:
+            assert r.state == "failed" and r.error == "cancelled" and len(r.output) < 48
+            assert r.output == want[i][:len(r.output)]
+        else:
+            assert r.state == "finished" and r.output == want[i], i
+    assert snap["cancelled"] == 4 and snap["failed"] == 0 and snap["completed"] == 20
+    assert snap["kv_blocks_used"] == 0 and snap["fatal"] is None
+
+
 def test_kv_mem_fraction_sizes_the_cache_from_free_device_memory():
     """No kv_blocks given: the cache takes `kv_mem_fraction` of what is free after weights and
     workspaces. Twice the fraction, about twice the blocks; the scheduler's pool is that size."""
