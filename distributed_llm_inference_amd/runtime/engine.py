@@ -74,6 +74,7 @@ class Request:
     done: threading.Event = field(default_factory=threading.Event)
     seed: int = 0
     callbacks: List = field(default_factory=list)     # called (from the scheduler thread) when the request is done
+    token_callbacks: List = field(default_factory=list)   # called (from the scheduler thread) after each output token
 
     def _set_done(self):
         self.done.set()
@@ -683,6 +684,12 @@ class Engine:
         r.output.append(tok)
         r.token_times.append(now)
         self.stats["tokens_out"] += 1
+        if r.token_callbacks:               # streaming listeners: they read `r.output` themselves
+            for cb in r.token_callbacks:
+                try:
+                    cb(r)
+                except Exception:
+                    pass
         if self.cfg.debug_top5 and len(r.output) % 5 == 0:      # progress line (orchestration.py:194-196)
             from ..utils.tracing import get_logger
             get_logger().info("request %d: %d tokens so far: %r", r.rid, len(r.output),

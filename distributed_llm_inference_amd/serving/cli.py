@@ -94,6 +94,7 @@ def main(argv=None) -> int:
     p.add_argument("--index", type=int, required=True, help="0-based worker index")
     p.add_argument("--num-workers", type=int, default=2)
     p = sub.add_parser("chat"); p.add_argument("url", nargs="?")
+    p.add_argument("--stream", action="store_true", help="print each answer while it is decoded (server-sent events)")
     p = sub.add_parser("generate"); _add_engine_args(p)
     p.add_argument("prompt"); p.add_argument("--max-tokens", type=int, default=20)
     p.add_argument("--temperature", type=float, default=None)
@@ -110,7 +111,7 @@ def main(argv=None) -> int:
         serve_worker(cfg, a.index, a.num_workers, port=a.port)
     elif a.cmd == "chat":
         from .client import main as client_main
-        return client_main([a.url] if a.url else [])
+        return client_main(([a.url] if a.url else []) + (["--stream"] if a.stream else []))
     elif a.cmd == "generate":
         from ..parallel.launcher import make_pipeline
         cfg = config_from_args(a)

@@ -22,9 +22,9 @@ class DistributedLLMClient:
         if check:
             self.check_health()
 
-    def _say(self, *a):
+    def _say(self, *a, **kw):
         if self.verbose:
-            print(*a)
+            print(*a, **kw)
 
     def check_health(self) -> bool:
         try:
@@ -84,6 +84,50 @@ class DistributedLLMClient:
             self._say(f"\nError: {e}")
             return None
 
+    def stream(self, prompt: str, max_tokens: int = 20, temperature: Optional[float] = None):
+        """Generator over the server-sent events of `POST /generate` with `"stream": true`: yields each
+        new piece of text as it is decoded; the final result dictionary (the one `generate` returns) is
+        left in `self.last_result`. Closing the generator early closes the connection, which cancels
+        the request on the server."""
+        import json
+        body = {"prompt": prompt, "max_tokens": max_tokens, "stream": True}
+        if temperature is not None:
+            body["temperature"] = temperature
+        self.last_result = None
+        with self._rq.post(f"{self.api_url}/generate", json=body, headers=self.headers, timeout=self.timeout,
+                           stream=True) as r:
+            if r.status_code != 200:
+                raise RuntimeError(f"HTTP Error {r.status_code}")
+            for line in r.iter_lines():
+                if not line or not line.startswith(b"data: "):
+                    continue
+                payload = line[6:]
+                if payload == b"[DONE]":
+                    break
+                d = json.loads(payload)
+                if "text" in d and "status" not in d:
+                    yield d["text"]
+                else:
+                    self.last_result = d
+
+    def generate_streaming(self, prompt: str, max_tokens: int = 20, temperature: Optional[float] = None) -> Optional[Dict]:
+        """`generate`, printing the text while it arrives."""
+        self._say("\n" + "=" * 60 + f"\nPrompt: {prompt}\n" + "=" * 60 + "\n\nResponse: ", end="")
+        try:
+            for piece in self.stream(prompt, max_tokens, temperature):
+                if self.verbose:
+                    print(piece, end="", flush=True)
+        except Exception as e:
+            self._say(f"\nError: {e}")
+            return None
+        d = self.last_result
+        if not d or "error" in d:
+            self._say(f"\nError: {(d or {}).get('error', 'no result')}")
+            return None
+        self._say(f"\n\nPerformance:\n   Time: {d.get('time_taken', 'N/A')}\n   Tokens: {d.get('tokens_generated', 'N/A')}"
+                  f"\n   Speed: {d.get('tokens_per_sec', 'N/A')} tok/s\n" + "=" * 60 + "\n")
+        return d
+
     def interactive_chat(self, input_fn=input, max_tokens: int = 15):
         self._say("\n" + "=" * 60 + "\nINTERACTIVE CHAT MODE\n" + "=" * 60)
         self._say("Commands:\n  - Type your question and press Enter\n  - 'quit' / 'exit' / 'q' - Exit\n"
@@ -103,7 +147,10 @@ class DistributedLLMClient:
                 if low == "health":
                     self.check_health()
                     continue
-                self.generate(user_input, max_tokens=max_tokens)        # Test.py:138
+                if getattr(self, "streaming", False):
+                    self.generate_streaming(user_input, max_tokens=max_tokens)
+                else:
+                    self.generate(user_input, max_tokens=max_tokens)    # Test.py:138
             except (KeyboardInterrupt, EOFError):
                 self._say("\n\nGoodbye!")
                 break
@@ -114,11 +161,14 @@ class DistributedLLMClient:
 def main(argv=None, input_fn=input):
     """The reference's start menu (Test.py:147-187)."""
     argv = sys.argv[1:] if argv is None else argv
+    flags = [x for x in argv if x.startswith("--")]
+    argv = [x for x in argv if not x.startswith("--")]
     api_url = argv[0] if argv else input_fn("Enter the API URL: ").strip()
     if not api_url:
         print("No URL provided!")
         return 1
     client = DistributedLLMClient(api_url)
+    client.streaming = "--stream" in flags             # print the text while it is decoded
     client.check_workers()
     print("\n" + "=" * 60 + "\nWhat would you like to do?\n1. Interactive chat (recommended)\n2. Single query\n3. Quick test\n" + "=" * 60)
     choice = input_fn("\nChoice (1/2/3): ").strip()

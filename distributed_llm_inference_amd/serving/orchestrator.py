@@ -6,6 +6,8 @@
     POST /generate  {"prompt": str, "max_tokens": int = 20, "temperature": float = 0.7}
                     -> 200 {"prompt","response","status":"success","time_taken":"N.NNs",
                             "tokens_generated":int,"tokens_per_sec":"N.NN"}
+                    with "stream": true (addition, ASGI server): text/event-stream of {"text","tokens_generated"}
+                    events, then that dictionary, then [DONE]
                        400 {"error":"No prompt provided"}; 500 {"error":"Orchestrator not initialized"};
                        200 {"error":"Error: ...","status":"failed"} on a runtime failure
     GET  /metrics   Prometheus text (addition)
@@ -114,6 +116,76 @@ class EngineBackend:
         finally:
             if watch is not None and not watch.done():
                 watch.cancel()
+
+    async def astream(self, prompt, max_new_tokens, temperature):
+        """Server-sent events for `POST /generate` with `"stream": true`: one
+        `data: {"text": <new text>, "tokens_generated": n}` event per decode step that produced
+        text, then the reference's result dictionary (or its error envelope) as the last JSON event,
+        then `data: [DONE]`. The scheduler thread only pokes an `asyncio.Event`; the coroutine reads
+        the request's output list itself, so no token is lost whatever the timing, and the text is
+        decoded from the whole output each time (tokens that end inside a multi-byte character are
+        held back until it is complete). A client that goes away closes the generator, which
+        cancels the request. The reference answers only when the whole text is there
+        (orchestration.py:201-218)."""
+        import asyncio
+        import json
+        loop = asyncio.get_running_loop()
+        if self.cfg.auto_restart and self.engine.fatal:
+            await loop.run_in_executor(None, self._recover)
+        start = time.time()
+        engine = self.engine
+        req = None
+
+        def event(obj):
+            return f"data: {json.dumps(obj)}\n\n"
+
+        try:
+            try:
+                req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k, self.cfg.top_p)
+            except Exception as e:
+                yield event({"error": f"Error: {e or type(e).__name__}", "status": "failed"})
+                yield "data: [DONE]\n\n"
+                return
+            news = asyncio.Event()
+
+            def poke(_req):
+                loop.call_soon_threadsafe(news.set)
+
+            req.token_callbacks.append(poke)
+            req.add_done_callback(poke)
+            deadline = loop.time() + self.cfg.request_timeout_s
+            seen, sent_text = 0, ""
+            while True:
+                news.clear()                    # before reading the state: a poke after the read wakes the wait below
+                done = req.done.is_set()
+                n = len(req.output)
+                if n > seen:
+                    seen = n
+                    text = engine.tok.decode(req.output[:n], skip_special_tokens=True)
+                    for _ in range(3):          # an unfinished multi-byte character decodes to <= 3 of these
+                        if done or not text.endswith("\ufffd"):
+                            break
+                        text = text[:-1]
+                    if text.startswith(sent_text) and len(text) > len(sent_text):
+                        yield event({"text": text[len(sent_text):], "tokens_generated": n})
+                        sent_text = text
+                if done:
+                    break
+                left = deadline - loop.time()
+                if left <= 0:
+                    engine.cancel(req)
+                    yield event({"error": f"Error: no result within {self.cfg.request_timeout_s:g}s", "status": "failed"})
+                    yield "data: [DONE]\n\n"
+                    return
+                try:
+                    await asyncio.wait_for(news.wait(), timeout=left)
+                except asyncio.TimeoutError:
+                    pass
+            yield event(engine.text_result(req, prompt, start))
+            yield "data: [DONE]\n\n"
+        finally:
+            if req is not None and not req.finished:
+                engine.cancel(req)              # the client closed the stream
 
     def workers(self) -> Dict[str, str]:
         """Stage s is reported as worker_{s+1}. online = ready with a fresh heartbeat; error = the
@@ -348,7 +420,7 @@ def create_asgi_app(backend):
     import json
 
     from starlette.applications import Starlette
-    from starlette.responses import HTMLResponse, JSONResponse, PlainTextResponse, Response
+    from starlette.responses import HTMLResponse, JSONResponse, PlainTextResponse, Response, StreamingResponse
     from starlette.routing import Route
 
     state = {"backend": backend}
@@ -390,6 +462,11 @@ def create_asgi_app(backend):
             temperature = float(data.get("temperature", b.cfg.temperature))
         except (TypeError, ValueError):
             return js({"error": "max_tokens and temperature must be numbers"}, 400)
+        if data.get("stream"):
+            if not hasattr(b, "astream"):
+                return js({"error": "streaming needs the pipeline engine behind this API"}, 400)
+            return StreamingResponse(b.astream(prompt, max_tokens, temperature), media_type="text/event-stream",
+                                     headers={**cors, "Cache-Control": "no-cache", "X-Accel-Buffering": "no"})
         if hasattr(b, "agenerate"):
             async def client_gone():            # the body has been read: the next message is the disconnect
                 while (await request.receive()).get("type") != "http.disconnect":

@@ -179,6 +179,66 @@ def test_a_client_that_disconnects_cancels_its_request(backend):
     assert eng.wait_idle(30) and eng.alloc.used == 0 and eng.stats["cancelled"] == before + 2
 
 
+def test_streaming_generate_sends_the_text_as_it_is_decoded(backend):
+    """`"stream": true`: server-sent events whose text pieces concatenate to the response of the final
+    result event, which is the dictionary a plain `/generate` returns; greedy tokens are the same with
+    and without streaming; closing the stream early cancels the request."""
+    import asyncio
+    from starlette.testclient import TestClient
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    eng = backend.engine
+    with TestClient(create_asgi_app(backend)) as c:
+        plain = c.post("/generate", json={"prompt": "Hello there", "max_tokens": 24, "temperature": 0}).json()
+        with c.stream("POST", "/generate", json={"prompt": "Hello there", "max_tokens": 24, "temperature": 0, "stream": True}) as r:
+            assert r.status_code == 200 and r.headers["content-type"].startswith("text/event-stream")
+            events = [l[6:] for l in r.iter_lines() if l.startswith("data: ")]
+        assert events[-1] == "[DONE]"
+        final = json.loads(events[-2])
+        pieces = [json.loads(e) for e in events[:-2]]
+        assert final["status"] == "success" and final["response"] == plain["response"]
+        assert final["tokens_generated"] == plain["tokens_generated"] == 24
+        assert len(pieces) > 1 and "".join(p["text"] for p in pieces) == final["response"]
+        assert [p["tokens_generated"] for p in pieces] == sorted(p["tokens_generated"] for p in pieces)
+        # a failing request: the error envelope is the only JSON event
+        with c.stream("POST", "/generate", json={"prompt": "x" * 4000, "stream": True}) as r:
+            events = [l[6:] for l in r.iter_lines() if l.startswith("data: ")]
+        assert events[-1] == "[DONE]" and json.loads(events[0])["status"] == "failed" and len(events) == 2
+
+    # a reader that stops after the first piece: the request is cancelled, its blocks come back
+    async def first_piece_only():
+        agen = backend.astream("tell me a long story", 150, 0.0)
+        first = await agen.__anext__()
+        await agen.aclose()
+        return first
+
+    before = eng.stats["cancelled"]
+    first = asyncio.run(first_piece_only())
+    assert first.startswith("data: {") and "text" in json.loads(first[6:])
+    assert eng.wait_idle(30) and eng.alloc.used == 0 and eng.stats["cancelled"] == before + 1
+
+
+def test_client_library_streams(backend):
+    """`DistributedLLMClient.stream` against a real uvicorn socket."""
+    import threading
+    import uvicorn
+    from distributed_llm_inference_amd.serving.client import DistributedLLMClient
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    port = _free_port()
+    server = uvicorn.Server(uvicorn.Config(create_asgi_app(backend), host="127.0.0.1", port=port, log_level="warning"))
+    t = threading.Thread(target=server.run, daemon=True)
+    t.start()
+    try:
+        _wait_http(f"http://127.0.0.1:{port}/health")
+        cl = DistributedLLMClient(f"http://127.0.0.1:{port}", verbose=False, check=False)
+        pieces = list(cl.stream("Hello there", max_tokens=12, temperature=0))
+        assert cl.last_result["status"] == "success" and "".join(pieces) == cl.last_result["response"]
+        assert cl.generate("Hello there", max_tokens=12, temperature=0)["response"] == cl.last_result["response"]
+        assert cl.generate_streaming("Hello there", max_tokens=5)["tokens_generated"] <= 5
+    finally:
+        server.should_exit = True
+        t.join(20)
+
+
 def test_orchestrator_not_initialised():
     c = create_app(None).test_client()
     r = c.post("/generate", json={"prompt": "x"})
