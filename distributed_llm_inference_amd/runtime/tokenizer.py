@@ -127,3 +127,29 @@ def encode_prompt(tokenizer, text: str) -> List[int]:
     if bos and text.startswith(bos):
         return tokenizer.encode(text, add_special_tokens=False)
     return tokenizer.encode(text)
+
+
+class IncrementalDetokenizer:
+    """Text of a growing token list, piece by piece, for streaming. Tokens [lo, mid) have been handed
+    out; the text of [lo, n) minus the text of [lo, mid) is what is new. Both are decoded from the same
+    start, so whatever the tokenizer does at the start of a string (dropping a leading space) cancels
+    out, and a step costs two decodes of a few tokens, not one of the whole output. A token that
+    ends inside a multi-byte character decodes to U+FFFD: the piece is held back until the rest has
+    arrived (at most 4 tokens: by then it is not an unfinished character but invalid output)."""
+
+    def __init__(self, tokenizer):
+        self.tok = tokenizer
+        self.lo = self.mid = 0
+
+    def push(self, ids: Sequence[int], final: bool = False) -> str:
+        """`ids`: all output tokens so far. Returns the new text ("" when nothing can be shown yet)."""
+        n = len(ids)
+        if n <= self.mid:
+            return ""
+        old = self.tok.decode(ids[self.lo:self.mid], skip_special_tokens=True)
+        text = self.tok.decode(ids[self.lo:n], skip_special_tokens=True)
+        if len(text) > len(old) and (final or not text.endswith("\ufffd") or n - self.mid >= 4):
+            self.lo, self.mid = self.mid, n
+            return text[len(old):]
+        return ""
+

@@ -29,7 +29,7 @@ import torch
 
 from ..config import EngineConfig
 from ..runtime.sampler import sample_token, top_candidates
-from ..runtime.tokenizer import build_prompt, encode_prompt
+from ..runtime.tokenizer import IncrementalDetokenizer, build_prompt, encode_prompt
 
 VERSION = "dlia-mi355x-0.1"
 _HEADERS = {"ngrok-skip-browser-warning": "true", "Content-Type": "application/json"}   # orchestration.py:91-94
@@ -122,9 +122,9 @@ class EngineBackend:
         `data: {"text": <new text>, "tokens_generated": n}` event per decode step that produced
         text, then the reference's result dictionary (or its error envelope) as the last JSON event,
         then `data: [DONE]`. The scheduler thread only pokes an `asyncio.Event`; the coroutine reads
-        the request's output list itself, so no token is lost whatever the timing, and the text is
-        decoded from the whole output each time (tokens that end inside a multi-byte character are
-        held back until it is complete). A client that goes away closes the generator, which
+        the request's output list itself, so no token is lost whatever the timing; text is decoded
+        incrementally (tokens that end inside a multi-byte character are held back until it is
+        complete). A client that goes away closes the generator, which
         cancels the request. The reference answers only when the whole text is there
         (orchestration.py:201-218)."""
         import asyncio
@@ -154,21 +154,14 @@ class EngineBackend:
             req.token_callbacks.append(poke)
             req.add_done_callback(poke)
             deadline = loop.time() + self.cfg.request_timeout_s
-            seen, sent_text = 0, ""
+            detok = IncrementalDetokenizer(engine.tok)
             while True:
                 news.clear()                    # before reading the state: a poke after the read wakes the wait below
                 done = req.done.is_set()
                 n = len(req.output)
-                if n > seen:
-                    seen = n
-                    text = engine.tok.decode(req.output[:n], skip_special_tokens=True)
-                    for _ in range(3):          # an unfinished multi-byte character decodes to <= 3 of these
-                        if done or not text.endswith("\ufffd"):
-                            break
-                        text = text[:-1]
-                    if text.startswith(sent_text) and len(text) > len(sent_text):
-                        yield event({"text": text[len(sent_text):], "tokens_generated": n})
-                        sent_text = text
+                piece = detok.push(req.output[:n], final=done)
+                if piece:
+                    yield event({"text": piece, "tokens_generated": n})
                 if done:
                     break
                 left = deadline - loop.time()

@@ -413,3 +413,24 @@ def test_balanced_partition_over_attention_and_mlp_blocks():
     assert [x.describe() for x in p] == ["0-2.5", "2.5-4"] and p[0].attn_layers == [0, 1, 2] and p[0].mlp_layers == [0, 1]
     assert p[1].attn_layers == [3] and p[1].mlp_layers == [2, 3]
     assert balanced_split_blocks(spec, 1) == [(0, 64)]
+
+
+def test_incremental_detokenizer_never_shows_half_a_character():
+    """Streaming text: pieces concatenate to the whole decode, a multi-byte character is held back
+    until its last byte is there, and invalid bytes do not hold the stream up for ever."""
+    from distributed_llm_inference_amd.runtime.tokenizer import ByteTokenizer, IncrementalDetokenizer
+    tok = ByteTokenizer()
+    text = "héllo wörld ✓ 日本語 ok"
+    ids = tok.encode(text, add_special_tokens=False)
+    d = IncrementalDetokenizer(tok)
+    pieces = [d.push(ids[:n], final=(n == len(ids))) for n in range(1, len(ids) + 1)]
+    assert "".join(pieces) == tok.decode(ids) == text
+    assert all("�" not in p for p in pieces) and pieces.count("") == len(ids) - len(text)
+    # several tokens at once, and nothing new
+    d = IncrementalDetokenizer(tok)
+    assert d.push(ids[:7]) + d.push(ids[:7]) + d.push(ids, final=True) == text
+    # output that is not text at all still streams, 4 tokens at a time
+    bad = [tok.encode("é", add_special_tokens=False)[0]] * 9
+    d = IncrementalDetokenizer(tok)
+    got = [d.push(bad[:n], final=(n == 9)) for n in range(1, 10)]
+    assert "".join(got) == tok.decode(bad) and [len(g) for g in got] == [0, 0, 0, 4, 0, 0, 0, 4, 1]
