@@ -26,11 +26,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-async def run_load(url, clients, requests, max_tokens, prompt_words, timeout):
+async def run_load(url, clients, requests, max_tokens, prompt_words, timeout, stream=False):
     """`clients` connections, each posting its share of `requests` one after the other (closed loop).
     aiohttp: with hundreds of open connections the client must not be what is measured."""
     import aiohttp
     lat, toks, fails = [], 0, 0
+    ttft = []
     todo = iter(range(requests))
     conn = aiohttp.TCPConnector(limit=clients, force_close=False)
     async with aiohttp.ClientSession(connector=conn, timeout=aiohttp.ClientTimeout(total=timeout)) as cl:
@@ -41,6 +42,25 @@ async def run_load(url, clients, requests, max_tokens, prompt_words, timeout):
                         "temperature": 0.7}
                 t0 = time.perf_counter()
                 try:
+                    if stream:                 # server-sent events: time to the first piece of text, then the result event
+                        body["stream"] = True
+                        d, first = {}, None
+                        async with cl.post(url + "/generate", json=body) as r:
+                            async for line in r.content:
+                                if not line.startswith(b"data: ") or line.startswith(b"data: [DONE]"):
+                                    continue
+                                ev = json.loads(line[6:])
+                                if first is None:
+                                    first = time.perf_counter() - t0
+                                if "status" in ev:
+                                    d = ev
+                            if r.status == 200 and d.get("status") == "success":
+                                toks += int(d["tokens_generated"])
+                                lat.append(time.perf_counter() - t0)
+                                ttft.append(first)
+                            else:
+                                fails += 1
+                        continue
                     async with cl.post(url + "/generate", json=body) as r:
                         d = await r.json()
                         if r.status == 200 and d.get("status") == "success":
@@ -54,8 +74,13 @@ async def run_load(url, clients, requests, max_tokens, prompt_words, timeout):
         await asyncio.gather(*(client() for _ in range(clients)))
         wall = time.perf_counter() - t0
     lat.sort()
+    ttft.sort()
     pick = lambda q: round(lat[min(len(lat) - 1, int(q * len(lat)))] * 1e3, 1) if lat else None
-    return {"requests": requests, "clients": clients, "failed": fails, "wall_s": round(wall, 3),
+    extra = {}
+    if ttft:
+        extra = {"stream": True, "client_ttft_ms_p50": round(ttft[len(ttft) // 2] * 1e3, 1),
+                 "client_ttft_ms_p99": round(ttft[min(len(ttft) - 1, int(0.99 * len(ttft)))] * 1e3, 1)}
+    return {**extra, "requests": requests, "clients": clients, "failed": fails, "wall_s": round(wall, 3),
             "requests_per_s": round((requests - fails) / wall, 2), "output_tokens_per_s": round(toks / wall, 1),
             "latency_ms_p50": pick(0.5), "latency_ms_p99": pick(0.99), "max_tokens": max_tokens}
 
@@ -79,6 +104,7 @@ def main():
     ap.add_argument("--timeout", type=float, default=600.0)
     ap.add_argument("--transport", default="auto", help="stage transport of the spawned orchestrator (gloo: stages may share one GPU)")
     ap.add_argument("--kv-dtype", default="bf16")
+    ap.add_argument("--stream", action="store_true", help="clients read server-sent events; reports the time to the first piece of text")
     ap.add_argument("--show-one", action="store_true", help="first print the whole JSON answer of one /generate")
     a = ap.parse_args()
     import resource                      # one socket per client
@@ -120,7 +146,7 @@ def main():
                               "client_wall_s": round(time.perf_counter() - t0, 3),
                               "workers": httpx.get(url + "/workers", timeout=30).json()}), flush=True)
         asyncio.run(run_load(url, min(a.clients, 8), min(a.requests, 16), a.max_tokens, a.prompt_words, a.timeout))   # warm-up
-        out = asyncio.run(run_load(url, a.clients, a.requests, a.max_tokens, a.prompt_words, a.timeout))
+        out = asyncio.run(run_load(url, a.clients, a.requests, a.max_tokens, a.prompt_words, a.timeout, stream=a.stream))
         out.update({"server": a.server if proc else "external", "model": a.model, "dtype": a.dtype, "pp_size": a.pp_size, "transport": a.transport,
                     "micro_batch": a.batch, "micro_batches": a.micro_batches})
         print(json.dumps(out))

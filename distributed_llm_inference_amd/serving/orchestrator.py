@@ -46,6 +46,7 @@ class EngineBackend:
         self.restarts = 0
         self._factory = factory
         self._restart_lock = threading.Lock()
+        self._streams = 0                   # open /generate streams (event-loop thread only)
 
     def _recover(self):
         """Elastic recovery: the reference needs a human to restart a dead worker and re-paste its
@@ -119,8 +120,8 @@ class EngineBackend:
 
     async def astream(self, prompt, max_new_tokens, temperature):
         """Server-sent events for `POST /generate` with `"stream": true`: one
-        `data: {"text": <new text>, "tokens_generated": n}` event per decode step that produced
-        text, then the reference's result dictionary (or its error envelope) as the last JSON event,
+        `data: {"text": <new text>, "tokens_generated": n}` event per wake-up with new tokens (every
+        decode step while few streams are open, every few steps when there are thousands), then the reference's result dictionary (or its error envelope) as the last JSON event,
         then `data: [DONE]`. The scheduler thread only pokes an `asyncio.Event`; the coroutine reads
         the request's output list itself, so no token is lost whatever the timing; text is decoded
         incrementally (tokens that end inside a multi-byte character are held back until it is
@@ -134,7 +135,7 @@ class EngineBackend:
             await loop.run_in_executor(None, self._recover)
         start = time.time()
         engine = self.engine
-        req = None
+        req, counted = None, False
 
         def event(obj):
             return f"data: {json.dumps(obj)}\n\n"
@@ -147,21 +148,28 @@ class EngineBackend:
                 yield "data: [DONE]\n\n"
                 return
             news = asyncio.Event()
+            poked = [False]
 
-            def poke(_req):
-                loop.call_soon_threadsafe(news.set)
+            def poke(_req):                     # scheduler thread: one cross-thread call per wake-up, not per token
+                if not poked[0]:
+                    poked[0] = True
+                    loop.call_soon_threadsafe(news.set)
 
             req.token_callbacks.append(poke)
-            req.add_done_callback(poke)
+            req.add_done_callback(lambda _r: loop.call_soon_threadsafe(news.set))
+            self._streams += 1
+            counted = True
             deadline = loop.time() + self.cfg.request_timeout_s
             detok = IncrementalDetokenizer(engine.tok)
+            sent_n, t_sent = 0, 0.0
             while True:
                 news.clear()                    # before reading the state: a poke after the read wakes the wait below
+                poked[0] = False
                 done = req.done.is_set()
                 n = len(req.output)
-                piece = detok.push(req.output[:n], final=done)
-                if piece:
-                    yield event({"text": piece, "tokens_generated": n})
+                if n > sent_n:
+                    yield event({"text": detok.push(req.output[:n], final=done), "tokens_generated": n})
+                    sent_n, t_sent = n, loop.time()
                 if done:
                     break
                 left = deadline - loop.time()
@@ -173,10 +181,18 @@ class EngineBackend:
                 try:
                     await asyncio.wait_for(news.wait(), timeout=left)
                 except asyncio.TimeoutError:
-                    pass
+                    continue
+                # One event loop serves every stream: the more of them, the longer each waits between
+                # events (several tokens per event), so that the loop — and the scheduler thread it
+                # shares the interpreter with — is not spent on per-token wake-ups.
+                pause = t_sent + self._streams * self.cfg.stream_cost_ms * 1e-3 - loop.time()
+                if pause > 0 and not req.done.is_set():
+                    await asyncio.sleep(pause)
             yield event(engine.text_result(req, prompt, start))
             yield "data: [DONE]\n\n"
         finally:
+            if counted:
+                self._streams -= 1
             if req is not None and not req.finished:
                 engine.cancel(req)              # the client closed the stream
 
