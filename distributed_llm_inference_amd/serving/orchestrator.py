@@ -4,6 +4,7 @@
     GET  /health    {"status":"healthy","role":"orchestrator","model":...,"version":...}
     GET  /workers   {"worker_1":"online"|"error"|"offline"|"not_configured", ...}
     POST /generate  {"prompt": str, "max_tokens": int = 20, "temperature": float = 0.7}
+                    (additions, all optional: "top_k": int, "top_p": float, "seed": int, "stream": bool)
                     -> 200 {"prompt","response","status":"success","time_taken":"N.NNs",
                             "tokens_generated":int,"tokens_per_sec":"N.NN"}
                     with "stream": true (addition, ASGI server): text/event-stream of {"text","tokens_generated"}
@@ -70,12 +71,13 @@ class EngineBackend:
             self.cfg, self.engine = self.pipe.cfg, self.pipe.engine
             self.restarts += 1
 
-    def generate(self, prompt, max_new_tokens, temperature):
+    def generate(self, prompt, max_new_tokens, temperature, top_k=None, top_p=None, seed=None):
         self._recover()
         return self.engine.generate_text(prompt, max_new_tokens=max_new_tokens, temperature=temperature,
-                                         top_k=self.cfg.top_k, top_p=self.cfg.top_p)
+                                         top_k=self.cfg.top_k if top_k is None else top_k,
+                                         top_p=self.cfg.top_p if top_p is None else top_p, seed=seed)
 
-    async def agenerate(self, prompt, max_new_tokens, temperature, client_gone=None):
+    async def agenerate(self, prompt, max_new_tokens, temperature, client_gone=None, top_k=None, top_p=None, seed=None):
         """`generate` for an event loop: the coroutine is resumed by the scheduler thread's
         completion callback, so thousands of requests can wait without a thread each.
         `client_gone`: optional coroutine function that returns once the client has disconnected.
@@ -90,7 +92,8 @@ class EngineBackend:
         engine = self.engine
         req = watch = None
         try:
-            req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k, self.cfg.top_p)
+            req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k if top_k is None else top_k,
+                                     self.cfg.top_p if top_p is None else top_p, seed)
             fut = loop.create_future()
 
             def wake(_req):
@@ -118,7 +121,7 @@ class EngineBackend:
             if watch is not None and not watch.done():
                 watch.cancel()
 
-    async def astream(self, prompt, max_new_tokens, temperature):
+    async def astream(self, prompt, max_new_tokens, temperature, top_k=None, top_p=None, seed=None):
         """Server-sent events for `POST /generate` with `"stream": true`: one
         `data: {"text": <new text>, "tokens_generated": n}` event per wake-up with new tokens (every
         decode step while few streams are open, every few steps when there are thousands), then the reference's result dictionary (or its error envelope) as the last JSON event,
@@ -142,7 +145,8 @@ class EngineBackend:
 
         try:
             try:
-                req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k, self.cfg.top_p)
+                req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k if top_k is None else top_k,
+                                         self.cfg.top_p if top_p is None else top_p, seed)
             except Exception as e:
                 yield event({"error": f"Error: {e or type(e).__name__}", "status": "failed"})
                 yield "data: [DONE]\n\n"
@@ -267,8 +271,10 @@ class HttpRelayBackend:
             raise RuntimeError(f"Worker at {url} failed: {r.text}")       # orchestration.py:121-122
         return torch.tensor(r.json()["hidden_states"])
 
-    def generate(self, prompt, max_new_tokens, temperature):
+    def generate(self, prompt, max_new_tokens, temperature, top_k=None, top_p=None, seed=None):
         start = time.time()
+        top_k = self.cfg.top_k if top_k is None else top_k
+        top_p = self.cfg.top_p if top_p is None else top_p
         self.stats["requests"] += 1
         if not self.urls or not all(self.urls):
             return {"error": "Workers not configured!", "status": "failed"}        # orchestration.py:84-88
@@ -294,8 +300,8 @@ class HttpRelayBackend:
                 cached = len(ids) if self.incremental else 0
                 logits = self.edge.head_logits(hidden[0, -1:, :])[0]
                 if self.cfg.debug_top5 and step < 3:                                      # orchestration.py:172-178
-                    debug.append(top_candidates(logits, temperature, self.cfg.top_k, self.cfg.top_p, 5))
-                nxt = sample_token(logits, temperature, self.cfg.top_k, self.cfg.top_p)
+                    debug.append(top_candidates(logits, temperature, top_k, top_p, 5))
+                nxt = sample_token(logits, temperature, top_k, top_p)
                 if eos is not None and nxt == eos:
                     break
                 ids = ids + [nxt]
@@ -346,6 +352,24 @@ class HttpRelayBackend:
         self.session.close()
 
 
+def sampling_extras(data: Dict) -> Dict:
+    """Optional per-request sampling fields of `/generate` (additions: the reference fixes top-k 50 and
+    top-p 0.9, orchestration.py:353-354): {"top_k": int >= 0 (0 = off), "top_p": 0 < float <= 1,
+    "seed": int}. ValueError on anything else."""
+    out = {}
+    if data.get("top_k") is not None:
+        out["top_k"] = int(data["top_k"])
+        if out["top_k"] < 0:
+            raise ValueError("top_k must be >= 0")
+    if data.get("top_p") is not None:
+        out["top_p"] = float(data["top_p"])
+        if not 0.0 < out["top_p"] <= 1.0:
+            raise ValueError("top_p must be in (0, 1]")
+    if data.get("seed") is not None:
+        out["seed"] = int(data["seed"]) & 0x7FFFFFFFFFFFFFFF
+    return out
+
+
 def create_app(backend):
     """Flask app exposing the orchestrator routes over `backend` (None = not initialised)."""
     from flask import Flask, Response, jsonify, request
@@ -392,9 +416,10 @@ def create_app(backend):
         try:
             max_tokens = min(int(max_tokens), b.cfg.max_tokens_cap)              # orchestration.py:347 (cap 30 there)
             temperature = float(temperature)
-        except (TypeError, ValueError):
-            return jsonify({"error": "max_tokens and temperature must be numbers"}), 400
-        return jsonify(b.generate(prompt, max_tokens, temperature))              # HTTP 200 even when status == failed
+            extra = sampling_extras(data)
+        except (TypeError, ValueError) as e:
+            return jsonify({"error": f"max_tokens, temperature, top_k, top_p and seed must be numbers ({e})"}), 400
+        return jsonify(b.generate(prompt, max_tokens, temperature, **extra))     # HTTP 200 even when status == failed
 
     @app.route("/metrics", methods=["GET"])
     def metrics():
@@ -469,20 +494,21 @@ def create_asgi_app(backend):
         try:
             max_tokens = min(int(data.get("max_tokens", b.cfg.default_max_tokens)), b.cfg.max_tokens_cap)   # orchestration.py:347
             temperature = float(data.get("temperature", b.cfg.temperature))
-        except (TypeError, ValueError):
-            return js({"error": "max_tokens and temperature must be numbers"}, 400)
+            extra = sampling_extras(data)
+        except (TypeError, ValueError) as e:
+            return js({"error": f"max_tokens, temperature, top_k, top_p and seed must be numbers ({e})"}, 400)
         if data.get("stream"):
             if not hasattr(b, "astream"):
                 return js({"error": "streaming needs the pipeline engine behind this API"}, 400)
-            return StreamingResponse(b.astream(prompt, max_tokens, temperature), media_type="text/event-stream",
+            return StreamingResponse(b.astream(prompt, max_tokens, temperature, **extra), media_type="text/event-stream",
                                      headers={**cors, "Cache-Control": "no-cache", "X-Accel-Buffering": "no"})
         if hasattr(b, "agenerate"):
             async def client_gone():            # the body has been read: the next message is the disconnect
                 while (await request.receive()).get("type") != "http.disconnect":
                     pass
-            return js(await b.agenerate(prompt, max_tokens, temperature, client_gone))   # HTTP 200 even when status == failed
+            return js(await b.agenerate(prompt, max_tokens, temperature, client_gone, **extra))   # HTTP 200 even when status == failed
         from starlette.concurrency import run_in_threadpool
-        return js(await run_in_threadpool(b.generate, prompt, max_tokens, temperature))
+        return js(await run_in_threadpool(lambda: b.generate(prompt, max_tokens, temperature, **extra)))
 
     async def metrics(request):
         b = state["backend"]

@@ -239,6 +239,26 @@ def test_client_library_streams(backend):
         t.join(20)
 
 
+def test_generate_takes_optional_top_k_top_p_and_seed(backend):
+    """Additions to the reference's body (it fixes top-k 50 / top-p 0.9 and has no seed): top_k = 1 is
+    greedy at any temperature, a seed makes a sampled answer reproducible, bad values are a 400."""
+    from starlette.testclient import TestClient
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    flask = create_app(backend).test_client()
+    with TestClient(create_asgi_app(backend)) as c:
+        greedy = c.post("/generate", json={"prompt": "Hi", "max_tokens": 12, "temperature": 0}).json()
+        k1 = c.post("/generate", json={"prompt": "Hi", "max_tokens": 12, "temperature": 1.5, "top_k": 1}).json()
+        assert k1["status"] == "success" and k1["response"] == greedy["response"]
+        body = {"prompt": "Hi", "max_tokens": 12, "temperature": 1.5, "top_k": 0, "top_p": 1.0, "seed": 1234}
+        a, b = c.post("/generate", json=body).json(), c.post("/generate", json=body).json()
+        other = c.post("/generate", json={**body, "seed": 99}).json()
+        assert a["status"] == "success" and a["response"] == b["response"] == flask.post("/generate", json=body).get_json()["response"]
+        assert other["status"] == "success"
+        for bad in ({"top_p": 0}, {"top_p": 1.5}, {"top_k": -1}, {"top_k": "many"}, {"seed": "x"}):
+            assert c.post("/generate", json={"prompt": "Hi", **bad}).status_code == 400
+            assert flask.post("/generate", json={"prompt": "Hi", **bad}).status_code == 400
+
+
 def test_orchestrator_not_initialised():
     c = create_app(None).test_client()
     r = c.post("/generate", json={"prompt": "x"})
