@@ -118,6 +118,26 @@ def build_prompt(tokenizer, user_message: str, system_prompt: str, mode: str = "
     return format_chat_prompt(user_message, system_prompt)
 
 
+def build_chat_prompt(tokenizer, messages, default_system: str, mode: str = "auto") -> str:
+    """A list of {"role": "system" | "user" | "assistant", "content": str} as one prompt that ends
+    where the assistant's next turn begins: the tokenizer's own chat template when it ships one
+    (mode "hf" / "auto"), else the Zephyr layout of the reference (orchestration.py:66) extended to
+    several turns. Without a system message `default_system` is used, as the reference does."""
+    msgs = [{"role": str(m.get("role", "user")), "content": str(m.get("content", ""))} for m in messages]
+    if not any(m["role"] == "system" for m in msgs):
+        msgs.insert(0, {"role": "system", "content": default_system})
+    if mode == "none":
+        return "\n".join(m["content"] for m in msgs if m["role"] != "system")
+    tk = getattr(tokenizer, "tk", None)
+    if mode in ("hf", "auto") and getattr(tokenizer, "chat_template", None) and tk is not None:
+        try:
+            return tk.apply_chat_template(msgs, tokenize=False, add_generation_prompt=True)
+        except Exception:
+            if mode == "hf":
+                raise
+    return "".join(f"<|{m['role']}|>\n{m['content']}</s>\n" for m in msgs) + "<|assistant|>\n"
+
+
 def encode_prompt(tokenizer, text: str) -> List[int]:
     """Token ids of a formatted prompt with exactly one BOS: a chat template that already begins
     with the BOS string (Llama-3-Instruct's `<|begin_of_text|>`) is encoded without the tokenizer

@@ -12,6 +12,7 @@
                        400 {"error":"No prompt provided"}; 500 {"error":"Orchestrator not initialized"};
                        200 {"error":"Error: ...","status":"failed"} on a runtime failure
     GET  /metrics   Prometheus text (addition)
+    /v1/models, /v1/completions, /v1/chat/completions   OpenAI-style routes (addition, ASGI server: openai_api.py)
 
 Two backends sit behind the same routes: `EngineBackend` (the pipeline engine: stages over
 RCCL / gloo / loopback, continuous batching) and `HttpRelayBackend` (the reference's topology —
@@ -20,9 +21,9 @@ parity). Handlers only enqueue and wait; all serving state lives in the engine's
 """
 from __future__ import annotations
 
-import threading
-
+import contextlib
 import itertools
+import threading
 import time
 from typing import Dict, List
 
@@ -77,23 +78,26 @@ class EngineBackend:
                                          top_k=self.cfg.top_k if top_k is None else top_k,
                                          top_p=self.cfg.top_p if top_p is None else top_p, seed=seed)
 
-    async def agenerate(self, prompt, max_new_tokens, temperature, client_gone=None, top_k=None, top_p=None, seed=None):
-        """`generate` for an event loop: the coroutine is resumed by the scheduler thread's
-        completion callback, so thousands of requests can wait without a thread each.
+    def _sampling(self, top_k, top_p):
+        return (self.cfg.top_k if top_k is None else top_k, self.cfg.top_p if top_p is None else top_p)
+
+    async def recover_if_needed(self):
+        import asyncio
+        if self.cfg.auto_restart and self.engine.fatal:
+            await asyncio.get_running_loop().run_in_executor(None, self._recover)   # rebuilding stage processes blocks
+
+    async def wait_request(self, req, client_gone=None):
+        """Waits on an event loop for a submitted request: the coroutine is resumed by the scheduler
+        thread's completion callback, so thousands of requests can wait without a thread each.
         `client_gone`: optional coroutine function that returns once the client has disconnected.
-        A request whose client left, or that outlived `request_timeout_s`, or whose handler task is
-        cancelled (server shutdown) is cancelled in the engine, which frees its row and KV blocks
-        instead of decoding to `max_tokens` for nobody."""
+        Returns None when the request is done; when its client left, or it outlived
+        `request_timeout_s`, the request is cancelled in the engine (which frees its row and KV
+        blocks instead of decoding to `max_tokens` for nobody) and the reason is returned. A handler
+        task cancelled at server shutdown cancels the request too."""
         import asyncio
         loop = asyncio.get_running_loop()
-        if self.cfg.auto_restart and self.engine.fatal:
-            await loop.run_in_executor(None, self._recover)       # rebuilding stage processes blocks
-        start = time.time()
-        engine = self.engine
-        req = watch = None
+        watch = None
         try:
-            req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k if top_k is None else top_k,
-                                     self.cfg.top_p if top_p is None else top_p, seed)
             fut = loop.create_future()
 
             def wake(_req):
@@ -105,64 +109,56 @@ class EngineBackend:
                 watch = asyncio.ensure_future(client_gone())
                 waiters.add(watch)
             done, _ = await asyncio.wait(waiters, timeout=self.cfg.request_timeout_s, return_when=asyncio.FIRST_COMPLETED)
-            if fut not in done:
-                engine.cancel(req)
-                why = "client disconnected" if watch is not None and watch in done \
-                    else f"no result within {self.cfg.request_timeout_s:g}s"
-                return {"error": f"Error: {why}", "status": "failed"}
-            return engine.text_result(req, prompt, start)
+            if fut in done:
+                return None
+            self.engine.cancel(req)
+            return "client disconnected" if watch is not None and watch in done \
+                else f"no result within {self.cfg.request_timeout_s:g}s"
         except asyncio.CancelledError:
-            if req is not None:
-                engine.cancel(req)
+            self.engine.cancel(req)
             raise
-        except Exception as e:                                      # HTTP 200 envelope, as the reference
-            return {"error": f"Error: {e or type(e).__name__}", "status": "failed"}
         finally:
             if watch is not None and not watch.done():
                 watch.cancel()
 
-    async def astream(self, prompt, max_new_tokens, temperature, top_k=None, top_p=None, seed=None):
-        """Server-sent events for `POST /generate` with `"stream": true`: one
-        `data: {"text": <new text>, "tokens_generated": n}` event per wake-up with new tokens (every
-        decode step while few streams are open, every few steps when there are thousands), then the reference's result dictionary (or its error envelope) as the last JSON event,
-        then `data: [DONE]`. The scheduler thread only pokes an `asyncio.Event`; the coroutine reads
-        the request's output list itself, so no token is lost whatever the timing; text is decoded
-        incrementally (tokens that end inside a multi-byte character are held back until it is
-        complete). A client that goes away closes the generator, which
-        cancels the request. The reference answers only when the whole text is there
-        (orchestration.py:201-218)."""
-        import asyncio
-        import json
-        loop = asyncio.get_running_loop()
-        if self.cfg.auto_restart and self.engine.fatal:
-            await loop.run_in_executor(None, self._recover)
+    async def agenerate(self, prompt, max_new_tokens, temperature, client_gone=None, top_k=None, top_p=None, seed=None):
+        """`generate` for an event loop (see `wait_request`)."""
+        await self.recover_if_needed()
         start = time.time()
         engine = self.engine
-        req, counted = None, False
-
-        def event(obj):
-            return f"data: {json.dumps(obj)}\n\n"
-
         try:
-            try:
-                req = engine.submit_text(prompt, max_new_tokens, temperature, self.cfg.top_k if top_k is None else top_k,
-                                         self.cfg.top_p if top_p is None else top_p, seed)
-            except Exception as e:
-                yield event({"error": f"Error: {e or type(e).__name__}", "status": "failed"})
-                yield "data: [DONE]\n\n"
-                return
-            news = asyncio.Event()
-            poked = [False]
+            req = engine.submit_text(prompt, max_new_tokens, temperature, *self._sampling(top_k, top_p), seed)
+            why = await self.wait_request(req, client_gone)
+            if why is not None:
+                return {"error": f"Error: {why}", "status": "failed"}
+            return engine.text_result(req, prompt, start)
+        except Exception as e:                                      # HTTP 200 envelope, as the reference
+            return {"error": f"Error: {e or type(e).__name__}", "status": "failed"}
 
-            def poke(_req):                     # scheduler thread: one cross-thread call per wake-up, not per token
-                if not poked[0]:
-                    poked[0] = True
-                    loop.call_soon_threadsafe(news.set)
+    async def pieces(self, req):
+        """Async generator over a submitted request's text as it is decoded: yields (new text,
+        tokens so far) once per wake-up with new tokens — every decode step while few streams are
+        open, every few steps when there are thousands. The scheduler thread only pokes an
+        `asyncio.Event`; the coroutine reads the request's output list itself, so no token is lost
+        whatever the timing; text is decoded incrementally (tokens that end inside a multi-byte
+        character are held back until it is complete). Ends when the request is done; raises
+        TimeoutError (request cancelled) after `request_timeout_s`; closing the generator early (the
+        client went away) cancels the request."""
+        import asyncio
+        loop = asyncio.get_running_loop()
+        engine = self.engine
+        news = asyncio.Event()
+        poked = [False]
 
-            req.token_callbacks.append(poke)
-            req.add_done_callback(lambda _r: loop.call_soon_threadsafe(news.set))
-            self._streams += 1
-            counted = True
+        def poke(_req):                     # scheduler thread: one cross-thread call per wake-up, not per token
+            if not poked[0]:
+                poked[0] = True
+                loop.call_soon_threadsafe(news.set)
+
+        req.token_callbacks.append(poke)
+        req.add_done_callback(lambda _r: loop.call_soon_threadsafe(news.set))
+        self._streams += 1
+        try:
             deadline = loop.time() + self.cfg.request_timeout_s
             detok = IncrementalDetokenizer(engine.tok)
             sent_n, t_sent = 0, 0.0
@@ -172,16 +168,13 @@ class EngineBackend:
                 done = req.done.is_set()
                 n = len(req.output)
                 if n > sent_n:
-                    yield event({"text": detok.push(req.output[:n], final=done), "tokens_generated": n})
+                    yield detok.push(req.output[:n], final=done), n
                     sent_n, t_sent = n, loop.time()
                 if done:
-                    break
+                    return
                 left = deadline - loop.time()
                 if left <= 0:
-                    engine.cancel(req)
-                    yield event({"error": f"Error: no result within {self.cfg.request_timeout_s:g}s", "status": "failed"})
-                    yield "data: [DONE]\n\n"
-                    return
+                    raise TimeoutError(f"no result within {self.cfg.request_timeout_s:g}s")
                 try:
                     await asyncio.wait_for(news.wait(), timeout=left)
                 except asyncio.TimeoutError:
@@ -192,13 +185,34 @@ class EngineBackend:
                 pause = t_sent + self._streams * self.cfg.stream_cost_ms * 1e-3 - loop.time()
                 if pause > 0 and not req.done.is_set():
                     await asyncio.sleep(pause)
-            yield event(engine.text_result(req, prompt, start))
-            yield "data: [DONE]\n\n"
         finally:
-            if counted:
-                self._streams -= 1
-            if req is not None and not req.finished:
-                engine.cancel(req)              # the client closed the stream
+            self._streams -= 1
+            if not req.finished:
+                engine.cancel(req)              # the deadline passed, or the client closed the stream
+
+    async def astream(self, prompt, max_new_tokens, temperature, top_k=None, top_p=None, seed=None):
+        """Server-sent events for `POST /generate` with `"stream": true`: one
+        `data: {"text": <new text>, "tokens_generated": n}` event per piece (see `pieces`), then the
+        reference's result dictionary (or its error envelope) as the last JSON event, then
+        `data: [DONE]`. The reference answers only when the whole text is there
+        (orchestration.py:201-218)."""
+        import json
+        await self.recover_if_needed()
+        start = time.time()
+        engine = self.engine
+
+        def event(obj):
+            return f"data: {json.dumps(obj)}\n\n"
+
+        try:
+            req = engine.submit_text(prompt, max_new_tokens, temperature, *self._sampling(top_k, top_p), seed)
+            async with contextlib.aclosing(self.pieces(req)) as pieces:     # closed with this generator, not by the collector
+                async for text, n in pieces:
+                    yield event({"text": text, "tokens_generated": n})
+            yield event(engine.text_result(req, prompt, start))
+        except Exception as e:
+            yield event({"error": f"Error: {e or type(e).__name__}", "status": "failed"})
+        yield "data: [DONE]\n\n"
 
     def workers(self) -> Dict[str, str]:
         """Stage s is reported as worker_{s+1}. online = ready with a fresh heartbeat; error = the
@@ -514,8 +528,11 @@ def create_asgi_app(backend):
         b = state["backend"]
         return PlainTextResponse(b.metrics() if b else "", media_type="text/plain; version=0.0.4", headers=cors)
 
-    app = Starlette(routes=[Route("/", home), Route("/health", health), Route("/workers", workers),
-                            Route("/generate", generate, methods=["POST", "OPTIONS"]), Route("/metrics", metrics)])
+    routes = [Route("/", home), Route("/health", health), Route("/workers", workers),
+              Route("/generate", generate, methods=["POST", "OPTIONS"]), Route("/metrics", metrics)]
+    from .openai_api import add_routes
+    add_routes(routes, state, cors)           # /v1/models, /v1/completions, /v1/chat/completions
+    app = Starlette(routes=routes)
     app.state.dlia = state
     return app
 

@@ -259,6 +259,70 @@ def test_generate_takes_optional_top_k_top_p_and_seed(backend):
             assert flask.post("/generate", json={"prompt": "Hi", **bad}).status_code == 400
 
 
+def test_openai_style_routes(backend):
+    """`/v1/completions` feeds the prompt as it is, `/v1/chat/completions` applies the chat template
+    (a single user message gives the prompt, hence the greedy tokens, of `/generate`); usage counts,
+    finish reasons, streaming chunks that concatenate to the non-streamed text, error envelopes."""
+    from starlette.testclient import TestClient
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    eng = backend.engine
+    with TestClient(create_asgi_app(backend)) as c:
+        assert c.get("/v1/models").json()["data"][0]["id"] == backend.model_name
+        ref = c.post("/generate", json={"prompt": "Hello", "max_tokens": 10, "temperature": 0}).json()
+        r = c.post("/v1/chat/completions", json={"model": "x", "messages": [{"role": "user", "content": "Hello"}],
+                                                 "max_tokens": 10, "temperature": 0})
+        d = r.json()
+        assert r.status_code == 200 and d["object"] == "chat.completion" and d["id"].startswith("chatcmpl-")
+        ch = d["choices"][0]
+        assert ch["message"] == {"role": "assistant", "content": ref["response"]} and ch["finish_reason"] == "length"
+        assert d["usage"]["completion_tokens"] == 10 and d["usage"]["total_tokens"] == d["usage"]["prompt_tokens"] + 10
+        # several turns and content parts
+        r = c.post("/v1/chat/completions", json={"messages": [
+            {"role": "system", "content": "Be brief."}, {"role": "user", "content": "Hi"},
+            {"role": "assistant", "content": "Hello!"}, {"role": "user", "content": [{"type": "text", "text": "And now?"}]}],
+            "max_tokens": 4, "temperature": 0})
+        assert r.status_code == 200 and r.json()["usage"]["completion_tokens"] <= 4
+
+        raw = c.post("/v1/completions", json={"prompt": "Hello", "max_tokens": 10, "temperature": 0}).json()
+        assert raw["object"] == "text_completion" and raw["usage"]["prompt_tokens"] == len(eng.tok.encode("Hello"))
+        assert raw["usage"]["prompt_tokens"] < d["usage"]["prompt_tokens"]          # no template around it
+        one = c.post("/v1/completions", json={"prompt": ["Hello"], "max_tokens": 10, "temperature": 0}).json()
+        assert one["choices"][0]["text"] == raw["choices"][0]["text"]
+        seeded = [c.post("/v1/completions", json={"prompt": "Hello", "max_tokens": 10, "seed": 7}).json()["choices"][0]["text"]
+                  for _ in range(2)]
+        assert seeded[0] == seeded[1]
+
+        for path, body in (("/v1/completions", {"prompt": "Hello", "max_tokens": 10, "temperature": 0, "stream": True}),
+                           ("/v1/chat/completions", {"messages": [{"role": "user", "content": "Hello"}], "max_tokens": 10,
+                                                     "temperature": 0, "stream": True})):
+            with c.stream("POST", path, json=body) as r:
+                assert r.status_code == 200 and r.headers["content-type"].startswith("text/event-stream")
+                events = [l[6:] for l in r.iter_lines() if l.startswith("data: ")]
+            assert events[-1] == "[DONE]"
+            chunks = [json.loads(e) for e in events[:-1]]
+            if path.endswith("chat/completions"):
+                assert chunks[0]["choices"][0]["delta"] == {"role": "assistant", "content": ""}
+                text = "".join(k["choices"][0]["delta"].get("content", "") for k in chunks)
+                assert text == ref["response"] and chunks[0]["object"] == "chat.completion.chunk"
+            else:
+                assert "".join(k["choices"][0]["text"] for k in chunks) == raw["choices"][0]["text"]
+            assert chunks[-1]["choices"][0]["finish_reason"] == "length" and chunks[-1]["usage"]["completion_tokens"] == 10
+            assert all(k["choices"][0]["finish_reason"] is None for k in chunks[:-1])
+
+        for path, body in (("/v1/completions", {}), ("/v1/completions", {"prompt": "x", "n": 2}),
+                           ("/v1/completions", {"prompt": "x", "top_p": 0}), ("/v1/chat/completions", {"messages": []}),
+                           ("/v1/chat/completions", {"messages": "hi"}), ("/v1/completions", {"prompt": "x", "max_tokens": "many"})):
+            r = c.post(path, json=body)
+            assert r.status_code == 400 and r.json()["error"]["type"] == "invalid_request_error", (path, body)
+        r = c.post("/v1/completions", json={"prompt": "x" * 4000})
+        assert r.status_code == 400 and "max_seq_len" in r.json()["error"]["message"]
+        assert c.options("/v1/chat/completions").status_code == 204
+    with TestClient(create_asgi_app(None)) as c:
+        assert c.post("/v1/completions", json={"prompt": "x"}).status_code == 500
+        assert c.get("/v1/models").json() == {"object": "list", "data": []}
+    assert eng.wait_idle(30) and eng.alloc.used == 0
+
+
 def test_orchestrator_not_initialised():
     c = create_app(None).test_client()
     r = c.post("/generate", json={"prompt": "x"})
