@@ -139,6 +139,20 @@ def test_http_api_over_the_gpu_pipeline():
         assert a["status"] == "success" and a["tokens_generated"] <= 8 and a["response"] == b["response"]
         d = c.post("/generate", json={"prompt": "Tell me more", "max_tokens": 12}).get_json()
         assert d["status"] == "success" and float(d["tokens_per_sec"]) > 0
+        # the ASGI front door: streamed, OpenAI-style and plain answers are the same greedy text
+        import json
+        from starlette.testclient import TestClient
+        from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+        with TestClient(create_asgi_app(backend)) as s:
+            with s.stream("POST", "/generate", json={"prompt": "Hello", "max_tokens": 8, "temperature": 0, "stream": True}) as r:
+                events = [l[6:] for l in r.iter_lines() if l.startswith("data: ")]
+            assert events[-1] == "[DONE]" and json.loads(events[-2])["response"] == a["response"]
+            assert "".join(json.loads(e)["text"] for e in events[:-2]) == a["response"]
+            o = s.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": "Hello"}], "max_tokens": 8,
+                                                     "temperature": 0}).json()
+            assert o["choices"][0]["message"]["content"] == a["response"] and o["usage"]["completion_tokens"] <= 8
+            k1 = s.post("/generate", json={"prompt": "Hello", "max_tokens": 8, "temperature": 1.3, "top_k": 1}).json()
+            assert k1["response"] == a["response"]              # per-request top-k reaches the device sampler
     finally:
         backend.close()
 
