@@ -3,7 +3,7 @@
 reference's API is the four routes of orchestration.py:230-356, which `orchestrator.py` keeps.
 
 Supported request fields: `prompt` (a string, or a list holding one string) / `messages`,
-`max_tokens`, `temperature`, `top_p`, `top_k` (extension), `seed`, `stream`, `n` (1 only). Other
+`max_tokens`, `temperature`, `top_p`, `top_k` (extension), `seed`, `stream`, `stop`, `n` (1 only). Other
 fields are ignored. `/v1/completions` feeds the prompt to the model as it is; `/v1/chat/completions`
 formats the messages with the tokenizer's chat template (the reference's Zephyr layout without one).
 Errors use the `{"error": {"message", "type", "code"}}` envelope with a 4xx / 5xx status.
@@ -51,6 +51,42 @@ def parse_sampling(data: Dict, cfg) -> SamplingParams:
                           max_new_tokens=min(max_tokens, cfg.max_tokens_cap), seed=seed)
 
 
+def parse_stop(data: Dict) -> List[str]:
+    stop = data.get("stop")
+    if stop is None:
+        return []
+    if isinstance(stop, str):
+        stop = [stop]
+    if not isinstance(stop, list) or len(stop) > 4 or not all(isinstance(x, str) and x for x in stop):
+        raise BadRequest("stop must be a non-empty string or a list of up to 4 of them")
+    return stop
+
+
+class StopFilter:
+    """Cuts streamed text at the first occurrence of any stop string. Text that could still turn out
+    to be the beginning of a stop string (the last `longest - 1` characters) is held back."""
+
+    def __init__(self, stops: List[str]):
+        self.stops, self.buf, self.hit = stops, "", False
+        self.hold = max((len(x) for x in stops), default=1) - 1
+
+    def feed(self, piece: str) -> str:
+        if self.hit:
+            return ""
+        self.buf += piece
+        cut = min((i for i in (self.buf.find(x) for x in self.stops) if i >= 0), default=-1)
+        if cut >= 0:
+            out, self.buf, self.hit = self.buf[:cut], "", True
+            return out
+        keep = min(self.hold, len(self.buf))
+        out, self.buf = self.buf[:len(self.buf) - keep], self.buf[len(self.buf) - keep:]
+        return out
+
+    def flush(self) -> str:
+        out, self.buf = ("" if self.hit else self.buf), ""
+        return out
+
+
 def _finish_reason(req, cfg) -> str:
     hit_cap = len(req.output) >= req.params.max_new_tokens or len(req.prompt_ids) + len(req.output) >= cfg.max_seq_len
     return "length" if hit_cap else "stop"
@@ -91,7 +127,7 @@ def add_routes(routes: List, state: Dict, cors: Dict):
             raise BadRequest("the body must be a JSON object")
         return data
 
-    async def run(request, b, kind: str, prompt_ids: List[int], sp: SamplingParams, stream: bool):
+    async def run(request, b, kind: str, prompt_ids: List[int], sp: SamplingParams, stream: bool, stops: List[str]):
         """Common tail of both POST routes. kind: "text_completion" | "chat.completion"."""
         await b.recover_if_needed()
         engine = b.engine
@@ -110,6 +146,33 @@ def add_routes(routes: List, state: Dict, cors: Dict):
 
         def failed():
             return _error(req.error or "generation failed", 500, "server_error")
+
+        async def filtered():
+            """(text, done-by-stop) pieces with the stop strings applied; the request is cancelled at a hit."""
+            f = StopFilter(stops)
+            async with contextlib.aclosing(b.pieces(req)) as pieces:
+                async for text, _n in pieces:
+                    out = f.feed(text) if stops else text
+                    if out:
+                        yield out
+                    if f.hit:
+                        return                  # leaving `pieces` open-ended closes it, which cancels the request
+            tail = f.flush()
+            if tail:
+                yield tail
+
+        def finish_reason():
+            return "stop" if req.error == "cancelled" or not req.finished else _finish_reason(req, b.cfg)
+
+        if not stream and stops:                # the text has to be watched while it grows
+            try:
+                text = "".join([t async for t in filtered()])
+            except TimeoutError as e:
+                return js(_error(str(e), 408, "timeout"), 408)
+            if req.state == "failed" and req.error != "cancelled":
+                return js(failed(), 500)
+            return js({"id": rid, "object": kind, "created": created, "model": b.model_name,
+                       "choices": [choice(text, finish_reason())], "usage": _usage(req)})
 
         if not stream:
             async def client_gone():
@@ -136,14 +199,13 @@ def add_routes(routes: List, state: Dict, cors: Dict):
             try:
                 if kind != "text_completion":
                     yield chunk(choice(None, None, first=True))
-                async with contextlib.aclosing(b.pieces(req)) as pieces:
-                    async for text, _n in pieces:
-                        if text:
-                            yield chunk(choice(text, None))
-                if req.state == "failed":
+                async with contextlib.aclosing(filtered()) as texts:
+                    async for text in texts:
+                        yield chunk(choice(text, None))
+                if req.state == "failed" and req.error != "cancelled":
                     yield f"data: {json.dumps(failed())}\n\n"
                 else:
-                    yield chunk(choice(None, _finish_reason(req, b.cfg)), _usage(req))
+                    yield chunk(choice(None, finish_reason()), _usage(req))
             except Exception as e:
                 yield f"data: {json.dumps(_error(str(e) or type(e).__name__, 500, 'server_error'))}\n\n"
             yield "data: [DONE]\n\n"
@@ -165,9 +227,10 @@ def add_routes(routes: List, state: Dict, cors: Dict):
             if not isinstance(prompt, str) or not prompt:
                 raise BadRequest("prompt must be a non-empty string (or a list holding one)")
             sp = parse_sampling(data, b.cfg)
+            stops = parse_stop(data)
         except BadRequest as e:
             return js(_error(str(e)), 400)
-        return await run(request, b, "text_completion", encode_prompt(b.engine.tok, prompt), sp, bool(data.get("stream")))
+        return await run(request, b, "text_completion", encode_prompt(b.engine.tok, prompt), sp, bool(data.get("stream")), stops)
 
     async def chat_completions(request):
         if request.method == "OPTIONS":
@@ -184,10 +247,11 @@ def add_routes(routes: List, state: Dict, cors: Dict):
                 if isinstance(m.get("content"), list):
                     m["content"] = "".join(p.get("text", "") for p in m["content"] if isinstance(p, dict))
             sp = parse_sampling(data, b.cfg)
+            stops = parse_stop(data)
         except BadRequest as e:
             return js(_error(str(e)), 400)
         text = build_chat_prompt(b.engine.tok, messages, b.cfg.system_prompt, b.cfg.chat_template)
-        return await run(request, b, "chat.completion", encode_prompt(b.engine.tok, text), sp, bool(data.get("stream")))
+        return await run(request, b, "chat.completion", encode_prompt(b.engine.tok, text), sp, bool(data.get("stream")), stops)
 
     routes += [Route("/v1/models", models),
                Route("/v1/completions", completions, methods=["POST", "OPTIONS"]),

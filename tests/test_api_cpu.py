@@ -309,6 +309,21 @@ def test_openai_style_routes(backend):
             assert chunks[-1]["choices"][0]["finish_reason"] == "length" and chunks[-1]["usage"]["completion_tokens"] == 10
             assert all(k["choices"][0]["finish_reason"] is None for k in chunks[:-1])
 
+        # stop strings: the text ends before the first hit, streamed or not, and the request stops decoding
+        full = c.post("/v1/completions", json={"prompt": "Hello", "max_tokens": 40, "temperature": 0}).json()["choices"][0]["text"]
+        assert len(full) >= 6
+        stop = full[3:5]
+        want = full[:full.find(stop)]
+        before = eng.stats["tokens_out"]
+        cut = c.post("/v1/completions", json={"prompt": "Hello", "max_tokens": 40, "temperature": 0, "stop": stop}).json()
+        assert cut["choices"][0]["text"] == want and cut["choices"][0]["finish_reason"] == "stop"
+        assert eng.wait_idle(30) and eng.stats["tokens_out"] - before < 40
+        with c.stream("POST", "/v1/completions", json={"prompt": "Hello", "max_tokens": 40, "temperature": 0,
+                                                       "stop": ["\x00never", stop], "stream": True}) as r:
+            chunks = [json.loads(l[6:]) for l in r.iter_lines() if l.startswith("data: ") and l != "data: [DONE]"]
+        assert "".join(k["choices"][0]["text"] for k in chunks) == want and chunks[-1]["choices"][0]["finish_reason"] == "stop"
+        assert c.post("/v1/completions", json={"prompt": "x", "stop": ["a", "b", "c", "d", "e"]}).status_code == 400
+
         for path, body in (("/v1/completions", {}), ("/v1/completions", {"prompt": "x", "n": 2}),
                            ("/v1/completions", {"prompt": "x", "top_p": 0}), ("/v1/chat/completions", {"messages": []}),
                            ("/v1/chat/completions", {"messages": "hi"}), ("/v1/completions", {"prompt": "x", "max_tokens": "many"})):

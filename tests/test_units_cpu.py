@@ -434,3 +434,15 @@ def test_incremental_detokenizer_never_shows_half_a_character():
     d = IncrementalDetokenizer(tok)
     got = [d.push(bad[:n], final=(n == 9)) for n in range(1, 10)]
     assert "".join(got) == tok.decode(bad) and [len(g) for g in got] == [0, 0, 0, 4, 0, 0, 0, 4, 1]
+
+
+def test_stop_filter_cuts_at_the_first_stop_string_across_piece_boundaries():
+    from distributed_llm_inference_amd.serving.openai_api import StopFilter
+    f = StopFilter(["END", "\n\n"])
+    out = [f.feed(p) for p in ["Hello wor", "ld. E", "N", "D and more", "ignored"]]
+    assert "".join(out) == "Hello world. " and f.hit and f.flush() == ""
+    assert all("E" not in o for o in out[1:])            # nothing that might be the start of a stop string goes out early
+    f = StopFilter(["END"])
+    assert "".join([f.feed("abc E"), f.feed("N"), f.feed("x")]) + f.flush() == "abc ENx" and not f.hit
+    f = StopFilter(["b", "abc"])
+    assert f.feed("xxabc") == "xx" and f.hit             # the earliest hit wins
