@@ -172,7 +172,7 @@ class Engine:
         # counters for /metrics
         self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
                       "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0,
-                      "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0}
+                      "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0, "rejected": 0}
         self.latencies: Deque[float] = collections.deque(maxlen=4096)     # per-token decode latencies (s)
         self.ttfts: Deque[float] = collections.deque(maxlen=1024)
 
@@ -213,6 +213,11 @@ class Engine:
             return req
         if len(req.prompt_ids) + 1 > self.cfg.max_seq_len:
             self._fail(req, f"prompt of {len(req.prompt_ids)} tokens exceeds max_seq_len {self.cfg.max_seq_len}")
+            return req
+        if self.cfg.max_queue > 0 and len(self.waiting) + len(self._inbox) >= self.cfg.max_queue:
+            # back-pressure: answering "try again" now beats an answer after the client's own deadline
+            self.stats["rejected"] += 1
+            self._fail(req, f"queue full ({self.cfg.max_queue} requests waiting)")
             return req
         self.stats["requests"] += 1
         self.stats["tokens_in"] += len(req.prompt_ids)

@@ -46,6 +46,8 @@ def _add_engine_args(ap):
     ap.add_argument("--prefill-chunk", type=int)
     ap.add_argument("--kv-blocks", type=int)
     ap.add_argument("--max-tokens-cap", type=int)
+    ap.add_argument("--max-queue", type=int, help="requests allowed to wait for a row before new ones are refused (0 = unbounded)")
+    ap.add_argument("--request-timeout-s", type=float, help="server-side deadline of a request; it is cancelled when it passes")
     ap.add_argument("--host")
     ap.add_argument("--port", type=int)
     ap.add_argument("--worker-urls", help="comma-separated worker URLs (HTTP relay mode)")
@@ -62,7 +64,7 @@ def config_from_args(a) -> EngineConfig:
     base = EngineConfig.from_env(EngineConfig.from_dict(base)).to_dict()
     for k in ("model", "dtype", "kv_dtype", "pp_size", "partition", "backend", "device", "transport", "max_batch", "num_micro_batches",
               "max_seq_len", "prefill_chunk", "kv_blocks", "max_tokens_cap", "host", "port", "seed", "fault_inject",
-              "trace_path", "kv_mem_fraction", "server"):
+              "trace_path", "kv_mem_fraction", "server", "max_queue", "request_timeout_s"):
         v = getattr(a, k, None)
         if v is not None:
             base[k] = v

@@ -26,6 +26,7 @@ def render(engine_snapshot: Dict, board=None, num_stages: int = 0) -> str:
     metric("requests_completed_total", s.get("completed"), "requests completed", "counter")
     metric("requests_failed_total", s.get("failed"), "requests failed", "counter")
     metric("requests_cancelled_total", s.get("cancelled"), "requests abandoned by their client (disconnect or timeout)", "counter")
+    metric("requests_rejected_total", s.get("rejected"), "requests refused because the queue was full", "counter")
     metric("tokens_generated_total", s.get("tokens_out"), "output tokens", "counter")
     metric("prompt_tokens_total", s.get("tokens_in"), "prompt tokens", "counter")
     metric("steps_total", s.get("steps"), "pipeline steps issued", "counter")

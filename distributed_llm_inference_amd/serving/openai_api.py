@@ -182,7 +182,10 @@ def add_routes(routes: List, state: Dict, cors: Dict):
             if why is not None:
                 return js(_error(why, 408, "timeout"), 408)
             if req.state == "failed":
-                return js(failed(), 400 if "exceeds max_seq_len" in (req.error or "") or "empty prompt" in (req.error or "") else 500)
+                err = req.error or ""
+                if err.startswith("queue full"):
+                    return js(_error(err, 429, "rate_limit_error"), 429)
+                return js(failed(), 400 if "exceeds max_seq_len" in err or "empty prompt" in err else 500)
             text = engine.tok.decode(req.output, skip_special_tokens=True)
             return js({"id": rid, "object": kind, "created": created, "model": b.model_name,
                        "choices": [choice(text, _finish_reason(req, b.cfg))], "usage": _usage(req)})

@@ -338,6 +338,37 @@ def test_openai_style_routes(backend):
     assert eng.wait_idle(30) and eng.alloc.used == 0
 
 
+def test_a_full_queue_refuses_new_requests_at_once():
+    """`max_queue`: with every row busy and the queue at its limit a new request fails immediately
+    (error envelope on /generate, 429 on the OpenAI-style routes) instead of waiting for its turn."""
+    from starlette.testclient import TestClient
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    b = EngineBackend(LocalPipeline(cfg(max_batch=2, num_micro_batches=1, max_queue=3, max_seq_len=400)))
+    try:
+        eng = b.engine
+        sp = SamplingParams(temperature=0.0, max_new_tokens=300, stop_on_eos=False)
+        held = [eng.submit([5, 6, 7], sp) for _ in range(2)]
+        deadline = time.time() + 60
+        while not all(r.output for r in held) and time.time() < deadline:
+            time.sleep(0.005)
+        queued = [eng.submit([8, 9], sp) for _ in range(3)]
+        time.sleep(0.05)
+        refused = eng.submit([8, 9], sp)
+        assert refused.done.is_set() and refused.state == "failed" and refused.error.startswith("queue full")
+        with TestClient(create_asgi_app(b)) as c:
+            r = c.post("/generate", json={"prompt": "Hi", "max_tokens": 4})
+            assert r.status_code == 200 and r.json()["status"] == "failed" and "queue full" in r.json()["error"]
+            r = c.post("/v1/completions", json={"prompt": "Hi", "max_tokens": 4})
+            assert r.status_code == 429 and r.json()["error"]["type"] == "rate_limit_error"
+            assert "dlia_requests_rejected_total 3" in c.get("/metrics").text
+            for q in held + queued:
+                eng.cancel(q)
+            assert eng.wait_idle(30)
+            assert c.post("/generate", json={"prompt": "Hi", "max_tokens": 4}).json()["status"] == "success"
+    finally:
+        b.close()
+
+
 def test_orchestrator_not_initialised():
     c = create_app(None).test_client()
     r = c.post("/generate", json={"prompt": "x"})
