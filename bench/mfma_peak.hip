@@ -52,6 +52,50 @@ __global__ __launch_bounds__(512) void mfma_loop(float* out, long* clocks, int i
   }
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// the same on v_mfma_f32_32x32x16_bf16: twice the multiply-adds per operand register read
+// (4 independent 32 x 32 accumulators per wave)
+__global__ __launch_bounds__(512) void mfma32_loop(float* out, long* clocks, int iters, unsigned seed) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  u32x4 a[2], b[2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j) {
+      unsigned h = (t * 2654435761u + (i * 4 + j) * 40503u + seed) * 2246822519u;
+      const unsigned lo = ((h & 0x807fu) | ((100u + (h >> 16) % 27u) << 7));
+      h = h * 3266489917u + 1u;
+      const unsigned hi = ((h & 0x807fu) | ((100u + (h >> 16) % 27u) << 7));
+      a[i][j] = seed ? (lo | (hi << 16)) : 0u;
+      b[i][j] = seed ? (hi | (lo << 16)) : 0u;
+    }
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+  const long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]),
+                                                              acc[i][j], 0, 0, 0);
+  }
+  const long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 16; ++k) s += acc[i][j][k];
+  out[t] = s;
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned w = t >> 6;
+    clocks[2 * w] = c1 - c0;
+    clocks[2 * w + 1] = r1 - r0;
+  }
+}
+
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // the same loop on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales): 4x the
@@ -101,12 +145,13 @@ int main() {
   hipMalloc(&clocks, waves * 16);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < 6; ++pass) {
     const unsigned seed = (pass & 1) == 0 ? 12345u : 0u;
-    const bool f8 = pass >= 2;
+    const bool f8 = pass >= 2 && pass < 4, big = pass >= 4;
     for (int rep = 0; rep < 3; ++rep) {                                    // the last repetition is reported
       hipEventRecord(e0);
-      if (f8) hipLaunchKernelGGL(mfma8_loop, dim3(blocks), dim3(threads), 0, 0, out, clocks, iters / 2, seed);
+      if (big) hipLaunchKernelGGL(mfma32_loop, dim3(blocks), dim3(threads), 0, 0, out, clocks, iters / 2, seed);
+      else if (f8) hipLaunchKernelGGL(mfma8_loop, dim3(blocks), dim3(threads), 0, 0, out, clocks, iters / 2, seed);
       else    hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(threads), 0, 0, out, clocks, iters, seed);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
@@ -118,11 +163,12 @@ int main() {
     double ghz = 0;
     for (long w = 0; w < waves; ++w) ghz += (double)h[2 * w] / (double)h[2 * w + 1] * 0.1;
     ghz /= waves;
-    const int n = f8 ? iters / 2 : iters;
-    const double flop = (double)waves * n * 16 * 2.0 * 16 * 16 * (f8 ? 128 : 32);
+    const int n = (f8 || big) ? iters / 2 : iters;
+    const int per_iter = big ? 8 : 16;                                       // MFMAs per wave and iteration
+    const double flop = (double)waves * n * per_iter * 2.0 * (big ? 32 * 32 * 16 : 16 * 16 * (f8 ? 128 : 32));
     printf("%s %s operands: %d CUs x 8 waves, %.2f ms, %.0f TFLOP/s, in-kernel clock %.2f GHz (%.1f cycles per MFMA and SIMD)\n",
-           f8 ? "e4m3 16x16x128" : "bf16 16x16x32 ", seed ? "random" : "zero  ", cus, ms, flop / (ms * 1e-3) / 1e12, ghz,
-           ghz * 1e9 * ms * 1e-3 / ((double)n * 16 * 2));
+           big ? "bf16 32x32x16 " : f8 ? "e4m3 16x16x128" : "bf16 16x16x32 ", seed ? "random" : "zero  ", cus, ms,
+           flop / (ms * 1e-3) / 1e12, ghz, ghz * 1e9 * ms * 1e-3 / ((double)n * per_iter * 2));
   }
   return 0;
 }
