@@ -61,7 +61,7 @@ constexpr float kNegInf = -__builtin_inff();
 // contexts); 1 walks all of them alone with no LDS and no barrier (decode over thousands of
 // (sequence, kv head) items, where a 160-token context is 5 blocks and 4 waves would take 2, 1, 1, 1).
 template <int D, int NT, bool KV8, int NW, bool PF>
-__device__ __forceinline__ void paged_attn_body(const AttnParams& p) {
+__device__ __forceinline__ void paged_attn_body(const AttnParams& p, long item) {
   constexpr int KS = D / 32;      // MFMA k-steps over the head dim (QK^T)
   constexpr int DT = D / 16;      // 16-row tiles of the head dim (PV)
   constexpr int NC = NT * 16;     // query columns per workgroup
@@ -70,7 +70,6 @@ __device__ __forceinline__ void paged_attn_body(const AttnParams& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, l15 = lane & 15, quad = lane >> 4;
   const int wave = NW == 1 ? 0 : threadIdx.x >> 6;
-  long item = blockIdx.x;
   const int split = (int)(item % p.splits); item /= p.splits;
   const int qtile = (int)(item % p.qtiles); item /= p.qtiles;
   const int kvh = (int)(item % p.Hkv);
@@ -345,13 +344,13 @@ __device__ __forceinline__ void paged_attn_body(const AttnParams& p) {
 }
 
 template <int D, int NT, bool KV8>
-__global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) { paged_attn_body<D, NT, KV8, 4, true>(p); }
+__global__ __launch_bounds__(256) void paged_attn_kernel(AttnParams p) { paged_attn_body<D, NT, KV8, 4, true>(p, blockIdx.x); }
 
 // One wave per item, one block in flight per wave, registers capped so that 3 waves share a SIMD:
 // latency is hidden by the other waves instead of by a second set of K/V registers.
 template <int D, bool KV8>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void paged_attn_lean_kernel(AttnParams p) {
-  paged_attn_body<D, 1, KV8, 1, false>(p);
+  paged_attn_body<D, 1, KV8, 1, false>(p, blockIdx.x);
 }
 
 // Merge split-KV partials. One workgroup per (b, kv head, query tile); thread -> (column, 4 dims).
