@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--timeout", type=float, default=600.0)
     ap.add_argument("--transport", default="auto", help="stage transport of the spawned orchestrator (gloo: stages may share one GPU)")
     ap.add_argument("--kv-dtype", default="bf16")
+    ap.add_argument("--decode-buckets", default="", help='passed to `serve --decode-buckets`, e.g. "8,64"')
     ap.add_argument("--stream", action="store_true", help="clients read server-sent events; reports the time to the first piece of text")
     ap.add_argument("--show-one", action="store_true", help="first print the whole JSON answer of one /generate")
     a = ap.parse_args()
@@ -121,6 +122,8 @@ def main():
                "--num-micro-batches", str(a.micro_batches), "--max-seq-len", str(a.max_seq_len),
                "--max-tokens-cap", str(max(a.max_tokens, 32)), "--host", "127.0.0.1", "--port", str(port),
                "--server", a.server, "--transport", a.transport, "--kv-dtype", a.kv_dtype]
+        if a.decode_buckets:
+            cmd += ["--decode-buckets", a.decode_buckets]
         t_spawn = time.time()
         proc = subprocess.Popen(cmd, cwd=ROOT, start_new_session=True)
         import httpx

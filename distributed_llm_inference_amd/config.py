@@ -43,6 +43,11 @@ class EngineConfig:
     kv_blocks: int = 0                     # KV blocks per stage (0 -> sized from free device memory, see kv_mem_fraction)
     kv_mem_fraction: float = 0.85          # share of the memory left after weights and workspaces that the KV cache takes
     use_graphs: bool = True                # hipGraph-captured decode
+    # Row counts (besides max_batch) for which a micro-batch keeps a captured decode step: with few
+    # sequences running, a step covers only the rows up to the highest one in use, rounded up to the
+    # next of these, instead of all max_batch rows (a single request on a 256-row micro-batch:
+    # the step of 8 rows instead of 256). [] = every decode step covers max_batch rows.
+    decode_buckets: List[int] = field(default_factory=list)
     max_inflight_steps: int = 2            # steps of one micro-batch issued ahead of their results
     # A running micro-batch stops to take waiting requests in (drain, prefill, restart its decode loop)
     # only when that fills at least this share of its rows, or the oldest waiter has waited this long:
@@ -75,6 +80,10 @@ class EngineConfig:
     auto_restart: bool = False             # rebuild the pipeline (new processes, new communicators) after a fatal stage failure
     # ---- fault injection (tests) ------------------------------------------------------
     fault_inject: str = ""                 # e.g. "stage1:exit@3", "stage1:stall@2:5.0", "stage0:raise@1"
+
+    def graph_sizes(self) -> List[int]:
+        """Ascending row counts of fixed-shape decode steps: the buckets below max_batch, then max_batch."""
+        return sorted({int(b) for b in self.decode_buckets if 0 < int(b) < self.max_batch}) + [self.max_batch]
 
     def __post_init__(self):
         if self.pp_size < 1:

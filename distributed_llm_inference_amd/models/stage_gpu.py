@@ -81,7 +81,7 @@ class GpuStage:
                  max_slots: int = 256, max_seq_len: int = 2048, num_blocks: Optional[int] = None,
                  max_tokens: int = 2048, max_batch: int = 64, use_graphs: bool = True,
                  kv_mem_fraction: float = 0.85, weight_dtype: str = "bf16", kv_dtype: str = "bf16",
-                 decode_states: int = 1, defer_kv: bool = False):
+                 decode_states: int = 1, defer_kv: bool = False, graph_sizes: Optional[List[int]] = None):
         """`num_blocks`: KV blocks of this stage's cache; None sizes it from the device memory that is
         free once weights and workspaces are resident (`kv_mem_fraction` of it, less what the
         `decode_states` micro-batch workspaces will take). `defer_kv`: do not allocate the cache
@@ -108,6 +108,8 @@ class GpuStage:
         self.max_blocks = (max_seq_len + BLOCK - 1) // BLOCK
         self.max_tokens = max(max_tokens, max_batch)
         self.max_batch = max_batch
+        # row counts a micro-batch may run its fixed-shape decode step at (ascending, max_batch last)
+        self.graph_sizes = sorted({int(b) for b in (graph_sizes or []) if 0 < int(b) < max_batch}) + [max_batch]
         self.use_graphs = use_graphs
         self.null_slot = max_slots            # extra block-table row that never owns blocks
         dev, bf = self.device, torch.bfloat16
@@ -179,7 +181,7 @@ class GpuStage:
         self.block_table = torch.full((max_slots + 1, self.max_blocks), -1, device=dev, dtype=torch.int32)
         if not defer_kv:
             self.allocate_kv(num_blocks if num_blocks is not None else self.kv_budget_blocks())
-        self._mbs: Dict[int, _MicroBatchState] = {}
+        self._mbs: Dict[tuple, _MicroBatchState] = {}      # (micro-batch, rows) -> static decode state
         self._gemm_cfg: Dict[tuple, tuple] = {}
         self._ones = torch.ones(H, device=dev, dtype=bf)
         self.scale = 1.0 / math.sqrt(spec.head_dim)
@@ -189,7 +191,7 @@ class GpuStage:
     def _new_work(self, rows: int) -> _Work:
         s, dev, bf = self.spec, self.device, torch.bfloat16
         z = lambda *shape, dt=bf: torch.zeros(*shape, device=dev, dtype=dt)
-        B = self.max_batch
+        B = min(rows, self.max_batch)            # sequences (sampled rows) a step over this workspace can have
         # GEMM workspace: split-K partials of the weight-streaming kernels (up to DECODE_ROWS rows) in
         # front, or the slabs of the large-M kernel's in-launch split-K; the last 4096 words are that
         # kernel's arrival counters and must stay zero between launches (nobody else writes there)
@@ -264,13 +266,15 @@ class GpuStage:
     def _decode_state_bytes(self) -> int:
         """What one decode micro-batch will allocate on first use (activations, split-K partials,
         logits), so the cache does not take memory the serving loop still needs."""
-        s, B = self.spec, self.max_batch
+        s = self.spec
         per_tok = 2 * (2 * s.hidden_size + s.qkv_size + s.q_size + s.intermediate_size)
-        n = B * per_tok + 4 * self._ws_floats + 4 * self.wk0.attn_ws.numel()
-        if self.plan.has_head:
-            n += B * (4 * self.vocab_pad + 2 * s.hidden_size)
-        if self.wmode == "fp8":
-            n += B * max(s.hidden_size, s.q_size, s.intermediate_size)
+        n = 0
+        for B in self.graph_sizes:               # one state per row count a micro-batch may run at
+            n += B * per_tok + 4 * self._ws_floats + 4 * self.wk0.attn_ws.numel() * B // self.max_batch
+            if self.plan.has_head:
+                n += B * (4 * self.vocab_pad + 2 * s.hidden_size)
+            if self.wmode == "fp8":
+                n += B * max(s.hidden_size, s.q_size, s.intermediate_size)
         return n
 
     def kv_budget_blocks(self, share: float = 1.0) -> int:
@@ -494,9 +498,12 @@ class GpuStage:
 
     # ---- graph-captured decode ------------------------------------------------------------
     def _mb_state(self, mb: int, B: int) -> _MicroBatchState:
-        st = self._mbs.get(mb)
-        if st is not None and st.B == B:
+        st = self._mbs.get((mb, B))
+        if st is not None:
             return st
+        if B not in self.graph_sizes:                      # an odd size (a test, a probe): it replaces the previous odd one
+            for k in [k for k in self._mbs if k[0] == mb and k[1] not in self.graph_sizes]:
+                del self._mbs[k]
         dev, H = self.device, self.spec.hidden_size
         i32 = lambda: torch.zeros(B, device=dev, dtype=torch.int32)
         st = _MicroBatchState(
@@ -506,7 +513,7 @@ class GpuStage:
             tokens=i32() if self.plan.has_head else None,
             temperature=torch.zeros(B, device=dev), top_k=i32(), top_p=torch.ones(B, device=dev),
             seeds=torch.zeros(B, device=dev, dtype=torch.int64), steps=i32(), wk=self._new_work(B))
-        self._mbs[mb] = st
+        self._mbs[(mb, B)] = st
         return st
 
     def _decode_body(self, st: _MicroBatchState):
@@ -576,6 +583,23 @@ class GpuStage:
             st.graph.replay()
             self.graph_replays += 1
         return st.tokens if self.plan.has_head else st.hidden_out
+
+    def warm_decode_states(self):
+        """With more than one decode step size (`decode_buckets`): allocate every micro-batch's static
+        buffers and capture its step at every size now, on padding rows, so that the first request to
+        run at a size — the first burst after a quiet hour — does not pay for a gigabyte of workspace
+        and a graph capture (measured: 2.6 s of a 512-client burst). One size only: left to first use."""
+        if not self.use_graphs or len(self.graph_sizes) < 2 or self.kv is None:
+            return
+        if not hasattr(self, "_arange"):
+            self._arange = torch.arange(self.max_batch + 1, device=self.device, dtype=torch.int32)
+        for mb in range(self.decode_states):
+            for B in self.graph_sizes:
+                st = self._mb_state(mb, B)
+                if st.graph is None:
+                    st.splits = st.splits_wanted = 1
+                    self._capture(st)
+        torch.cuda.synchronize(self.device)
 
     def input_buffer(self, mb: int, B: int) -> torch.Tensor:
         st = self._mb_state(mb, B)

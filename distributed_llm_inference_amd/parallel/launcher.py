@@ -97,7 +97,8 @@ def build_executor(cfg: EngineConfig, spec: ModelSpec, plan: StagePlan, device: 
                         max_seq_len=cfg.max_seq_len, num_blocks=cfg.kv_blocks if cfg.kv_blocks > 0 else None,
                         max_tokens=cfg.prefill_chunk, max_batch=cfg.max_batch, use_graphs=cfg.use_graphs,
                         kv_mem_fraction=cfg.kv_mem_fraction, weight_dtype=cfg.dtype if cfg.dtype in ("fp8", "fp8w") else "bf16",
-                        kv_dtype=cfg.kv_dtype, decode_states=cfg.num_micro_batches, defer_kv=defer_kv)
+                        kv_dtype=cfg.kv_dtype, decode_states=cfg.num_micro_batches, defer_kv=defer_kv,
+                        graph_sizes=cfg.graph_sizes())
     if cfg.kv_dtype != "bf16":
         raise ValueError(f"kv_dtype {cfg.kv_dtype!r} needs the hip backend (the torch executor keeps its cache in the compute dtype)")
     from ..models.stage_ref import RefStage
@@ -116,6 +117,8 @@ def kv_budget(cfg: EngineConfig, ex, share: float = 1.0) -> int:
 def settle_kv(ex, blocks: int):
     if hasattr(ex, "allocate_kv") and ex.kv is None:
         ex.allocate_kv(blocks)
+    if hasattr(ex, "warm_decode_states"):
+        ex.warm_decode_states()          # with decode buckets: every size's state and graph exist before the first request
 
 
 def make_tokenizer(cfg: EngineConfig, spec: ModelSpec):
@@ -352,30 +355,41 @@ class SpawnedPipeline:
         from .transport import ShmControl
         self.cfg = cfg
         world = cfg.pp_size
-        self.job = f"dlia_{os.getpid()}_{uuid.uuid4().hex[:8]}"
-        port = _free_port()
         ctx = mp.get_context("spawn")
         self.spec = resolve_spec(cfg)
         self.plans = plans_for(cfg, self.spec)
-        # board and scheduler rings exist before the children attach
-        self.board = StatusBoard(self.job + "_b", create=True, num_stages=world)
-        slot = ctrl_slot_bytes(cfg)
-        self.cin = ShmControl(f"{self.job}_cin", create=True, slot_bytes=slot)
-        self.res = ShmControl(f"{self.job}_res", create=True, slot_bytes=max(1 << 14, 64 + 4 * cfg.max_batch + 2048))
-        self.procs = []
         self.engine = None
-        for r in range(world):
-            p = ctx.Process(target=_stage_entry, args=(cfg.to_dict(), r, world, self.job, port), daemon=True)
-            p.start()
-            self.procs.append(p)
-        try:
-            self.wait_ready(ready_timeout)
-        except BaseException:
-            self.kill()
-            raise
+        for attempt in range(3):
+            self.job = f"dlia_{os.getpid()}_{uuid.uuid4().hex[:8]}"
+            port = _free_port()
+            # board and scheduler rings exist before the children attach
+            self.board = StatusBoard(self.job + "_b", create=True, num_stages=world)
+            slot = ctrl_slot_bytes(cfg)
+            self.cin = ShmControl(f"{self.job}_cin", create=True, slot_bytes=slot)
+            self.res = ShmControl(f"{self.job}_res", create=True, slot_bytes=max(1 << 14, 64 + 4 * cfg.max_batch + 2048))
+            self.procs = []
+            for r in range(world):
+                p = ctx.Process(target=_stage_entry, args=(cfg.to_dict(), r, world, self.job, port), daemon=True)
+                p.start()
+                self.procs.append(p)
+            try:
+                self.wait_ready(ready_timeout)
+                break
+            except BaseException as e:
+                self.kill()
+                # The rendezvous port was free when picked, but another socket of this machine may take it
+                # before rank 0 listens on it: that attempt is discarded whole and made again on a new port.
+                clash = isinstance(e, RuntimeError) and ("failed to listen" in str(e) or "ddress already in use" in str(e))
+                if not clash or attempt == 2:
+                    raise
+                for obj in (self.cin, self.res, self.board):
+                    try:
+                        obj.close()
+                    except Exception:
+                        pass
         self.kv_blocks = min(self.board.read(s)["kv_blocks"] for s in range(world))
         hip = cfg.resolved_backend() == "hip"
-        head = RemoteHead(self.spec, world, self.cin, self.res, graph_capable=hip, graph_rows=cfg.max_batch,
+        head = RemoteHead(self.spec, world, self.cin, self.res, graph_capable=hip, graph_rows=cfg.graph_sizes(),
                           debug_top5=cfg.debug_top5, timeout_s=cfg.hop_timeout_s * world)
         self.tracer = make_tracer(cfg.trace_path)
         self.tokenizer = make_tokenizer(cfg, self.spec)

@@ -101,7 +101,7 @@ class StageRuntime:
         leaves the micro-batch's captured state alone."""
         ex = self.ex
         return (desc.is_decode and hasattr(ex, "decode_step") and not self.debug_top5
-                and desc.num_seqs == getattr(ex, "max_batch", desc.num_seqs))
+                and desc.num_seqs in getattr(ex, "graph_sizes", (desc.num_seqs,)))
 
     def result_count(self, desc: StepBatch) -> int:
         """Number of token ids the last stage produces for `desc`: a static-buffer decode step
@@ -110,7 +110,7 @@ class StageRuntime:
 
     def fb_buffer(self, mb: int, n: int) -> torch.Tensor:
         """Stage 0: where the fed-back tokens of micro-batch `mb` land."""
-        if hasattr(self.ex, "input_buffer") and self.ex.plan.has_embed and n == getattr(self.ex, "max_batch", -1):
+        if hasattr(self.ex, "input_buffer") and self.ex.plan.has_embed and n in getattr(self.ex, "graph_sizes", ()):
             return self.ex.input_buffer(mb, n)      # the static token buffer the decode graph reads
         key = (mb, n)
         b = self._fb_bufs.get(key)

@@ -121,6 +121,7 @@ class _MicroBatch:
         self.inflight: Deque[_Inflight] = collections.deque()
         self.state = "idle"           # idle | steady | draining | prefill
         self.fresh: List[Request] = []    # admitted, prefill not finished
+        self.nrows = size                 # rows a decode step of the current composition covers (a graph size)
         self.starved = False          # a decode step could not be issued: the KV pool had no block for a row
 
     def live(self) -> List[Request]:
@@ -169,6 +170,7 @@ class Engine:
         probe = StepBatch(slots=list(range(B)), q_lens=[1] * B, ctx_lens=[0] * B, sample=[1] * B, temperature=[0.0] * B,
                           top_k=[1] * B, top_p=[1.0] * B, seeds=[0] * B, sample_steps=[0] * B)
         self._static_decode = bool(head.graph_decode(probe))
+        self._graph_sizes = cfg.graph_sizes() if self._static_decode else [B]
         # counters for /metrics
         self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
                       "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0,
@@ -599,8 +601,14 @@ class Engine:
         """Issues one decode step of `mb`. False (nothing issued) when a row needs a KV block the
         pool does not have."""
         compact = replay and self._static_decode       # stages replay a captured graph: no per-row fields needed
+        if not replay:
+            # a new composition: its decode steps cover the rows up to the highest one in use, rounded
+            # up to the next size the stages keep a captured step for (rows are handed out lowest first)
+            top = max((i + 1 for i, r in enumerate(mb.rows) if r is not None and r.state == "running"), default=0)
+            mb.nrows = next((b for b in self._graph_sizes if b >= top), len(mb.rows))
+        n_rows = mb.nrows
         if compact:
-            d = StepBatch.replay_of(self._next_step_id(), mb.idx, len(mb.rows), 0)
+            d = StepBatch.replay_of(self._next_step_id(), mb.idx, n_rows, 0)
         else:
             d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, replay=replay,
                           token_ids=None if replay else [])
@@ -609,7 +617,7 @@ class Engine:
         rows: List[Optional[Request]] = []
         if compact:
             n_live = 0
-            for r in mb.rows:
+            for r in mb.rows[:n_rows]:
                 live = r is not None and r.state == "running"
                 if live:
                     r.issued_ctx += 1
@@ -620,9 +628,9 @@ class Engine:
             self.stats["decode_steps"] += 1
             self._submit(mb, d, rows)
             return True
-        for i, r in enumerate(mb.rows):
+        for i, r in enumerate(mb.rows[:n_rows]):
             live = r is not None and r.state == "running"
-            # fixed shape: every row of the micro-batch is present, dead/empty ones as padding
+            # fixed shape: every row of the step is present, dead/empty ones as padding
             d.slots.append(r.slot if r is not None else mb.idx * self.cfg.max_batch + i)
             d.q_lens.append(1 if live else 0)
             d.ctx_lens.append(r.issued_ctx if live else 0)

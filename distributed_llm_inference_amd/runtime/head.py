@@ -213,20 +213,20 @@ class RemoteHead:
     remote = True
     on_gpu = False          # nothing in this process touches a device
 
-    def __init__(self, spec, num_stages: int, cin, res, graph_capable: bool, graph_rows: int,
+    def __init__(self, spec, num_stages: int, cin, res, graph_capable: bool, graph_rows,
                  debug_top5: bool = False, timeout_s: float = 60.0):
         """`graph_capable` / `graph_rows`: whether the stages run fixed-shape decode steps over static
-        buffers (HIP executor) and the row count of such a step — the same rule the stages apply
-        (`StageRuntime._graph_decode`), needed here to know how many token ids a step returns."""
+        buffers (HIP executor) and the row counts of such steps (one, or a list) — the same rule the
+        stages apply (`StageRuntime._graph_decode`), needed here to know how many token ids a step returns."""
         self.spec, self.num_stages = spec, num_stages
         self.cin, self.res = cin, res
         self.graph_capable = graph_capable and not debug_top5
-        self.graph_rows = graph_rows
+        self.graph_rows = frozenset(graph_rows) if isinstance(graph_rows, (list, tuple, set, frozenset)) else frozenset([graph_rows])
         self.timeout_s = timeout_s
         self._arrived: Dict[int, tuple] = {}
 
     def graph_decode(self, desc: StepBatch) -> bool:
-        return self.graph_capable and desc.is_decode and desc.num_seqs == self.graph_rows
+        return self.graph_capable and desc.is_decode and desc.num_seqs in self.graph_rows
 
     def result_count(self, desc: StepBatch) -> int:
         return desc.num_seqs if self.graph_decode(desc) else desc.num_samples

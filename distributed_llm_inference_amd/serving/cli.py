@@ -46,6 +46,8 @@ def _add_engine_args(ap):
     ap.add_argument("--prefill-chunk", type=int)
     ap.add_argument("--kv-blocks", type=int)
     ap.add_argument("--max-tokens-cap", type=int)
+    ap.add_argument("--decode-buckets", help='row counts below --max-batch with a captured decode step of their own, e.g. "8,64": '
+                                             "with few sequences running a step covers that many rows instead of all")
     ap.add_argument("--max-queue", type=int, help="requests allowed to wait for a row before new ones are refused (0 = unbounded)")
     ap.add_argument("--request-timeout-s", type=float, help="server-side deadline of a request; it is cancelled when it passes")
     ap.add_argument("--host")
@@ -70,6 +72,8 @@ def config_from_args(a) -> EngineConfig:
             base[k] = v
     if getattr(a, "layer_ranges", None):
         base["layer_ranges"] = [tuple(int(x) for x in p.split("-")) for p in a.layer_ranges.split(",")]
+    if getattr(a, "decode_buckets", None):
+        base["decode_buckets"] = [int(x) for x in a.decode_buckets.split(",") if x.strip()]
     if getattr(a, "worker_urls", None):
         base["worker_urls"] = [u for u in a.worker_urls.split(",") if u]
     if getattr(a, "no_graphs", False):

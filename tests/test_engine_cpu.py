@@ -221,6 +221,30 @@ def test_multiprocess_gloo_pipeline_matches_local():
         pipe.close()
 
 
+def test_stage_bring_up_is_made_again_when_the_rendezvous_port_was_taken(monkeypatch):
+    """The rendezvous port is picked before the stage processes exist; if another socket holds it by
+    the time rank 0 listens, that attempt is discarded (processes, board, rings) and made again."""
+    import socket
+    from distributed_llm_inference_amd.parallel import launcher
+    taken = socket.socket()
+    taken.bind(("127.0.0.1", 0))
+    taken.listen(1)
+    real, calls = launcher._free_port, []
+
+    def first_the_taken_one():
+        calls.append(1)
+        return taken.getsockname()[1] if len(calls) == 1 else real()
+
+    monkeypatch.setattr(launcher, "_free_port", first_the_taken_one)
+    pipe = make_pipeline(cfg(pp_size=2, num_micro_batches=2, transport="gloo", partition="even"))
+    try:
+        assert len(calls) == 2
+        assert len(run(pipe, prompts(2, seed=5), greedy(4))) == 2
+    finally:
+        pipe.close()
+        taken.close()
+
+
 def test_trace_file_has_step_and_scheduler_events(tmp_path):
     """`trace_path` produces one Chrome-trace JSON holding the host timeline of every stage and
     the scheduler's admit / finish marks."""

@@ -406,6 +406,39 @@ def test_decode_graph_is_captured_once_across_recompositions_on_a_two_stage_pipe
         pipe.close()
 
 
+@pytest.mark.parametrize("pp", [1, 2])
+def test_decode_steps_shrink_to_the_rows_in_use(pp):
+    """`decode_buckets`: with few sequences running a micro-batch's decode step covers 4 or 16 rows
+    instead of all 64 (its own captured graph and static buffers per size), grows back under load,
+    and the tokens are those of an engine that always runs 64 rows."""
+    few, many = prompts(3, seed=31), prompts(70, seed=32)
+    want_few, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64), few, greedy(20))
+    want_many, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64), many, greedy(12), timeout=300)
+    c = cfg(pp_size=pp, num_micro_batches=2, max_batch=64, decode_buckets=[4, 16, 200])
+    assert c.graph_sizes() == [4, 16, 64]
+    pipe = LocalPipeline(c)
+    try:
+        eng = pipe.engine
+        for ex in pipe.executors:                                   # every size of every micro-batch captured at bring-up
+            assert ex.graph_captures == 2 * 3 and {k[1] for k in ex._mbs} == {4, 16, 64}
+        got_few = [r.wait(120).output for r in [eng.submit(p, greedy(20)) for p in few]]
+        assert min(mb.nrows for mb in eng.mbs) == 4                 # 3 requests on one micro-batch: 4-row steps
+        got_many = [r.wait(300).output for r in [eng.submit(p, greedy(12)) for p in many]]
+        assert max(mb.nrows for mb in eng.mbs) == 64
+        again = [r.wait(120).output for r in [eng.submit(p, greedy(20)) for p in few]]
+        assert eng.wait_idle(30) and min(mb.nrows for mb in eng.mbs) == 4
+        snap = eng.snapshot()
+        for ex in pipe.executors:
+            assert ex.graph_captures == 2 * 3 and ex.graph_replays > 0
+    finally:
+        pipe.close()
+    same = lambda a, b: sum(x == y for o1, o2 in zip(a, b) for x, y in zip(o1, o2)) / sum(len(o) for o in a)
+    # the kernels pick their split-K by row count, so a 4-row step may round differently from a 64-row one
+    assert same(got_few, want_few) >= 0.9 and same(again, want_few) >= 0.9 and got_few == again
+    assert same(got_many, want_many) >= 0.9
+    assert snap["failed"] == 0 and snap["fatal"] is None and snap["kv_blocks_used"] == 0
+
+
 def test_single_stage_process_serves_replay_steps_natively(tmp_path, monkeypatch):
     """`isolate`: the one stage lives in a child process whose loop is C++ in steady state (descriptor
     ring -> block-table growth -> hipGraphLaunch -> token copy -> result ring). Same tokens as the
@@ -499,6 +532,35 @@ def test_stage_processes_over_native_rccl_hops_give_the_single_stage_tokens(pp, 
     finally:
         pipe.close()
     assert got == ref
+
+
+@pytest.mark.parametrize("shape", ["one stage process, native serving loop", "two stage processes over native RCCL hops"])
+def test_decode_buckets_in_stage_processes(shape, monkeypatch):
+    """Decode steps of 4 rows and of 32 rows alternate as the load changes, with the stages in their
+    own processes: the native loops are handed each size's captured step, static buffers and message
+    sizes at the recomposition that switches to it."""
+    from distributed_llm_inference_amd.parallel.launcher import make_pipeline
+    monkeypatch.setenv("DLIA_SHARE_GPU", "1")
+    monkeypatch.setenv("DLIA_RCCL_DISTINCT_HOSTS", "1")
+    few, many = prompts(2, seed=41), [p * 2 for p in prompts(40, seed=42)]
+    want_few, _ = run(cfg(max_batch=32), few, greedy(40))
+    want_many, _ = run(cfg(max_batch=32), many, greedy(16), timeout=300)
+    extra = dict(isolate=True) if shape.startswith("one") else dict(pp_size=2, num_micro_batches=3, transport="rccl")
+    pipe = make_pipeline(cfg(max_batch=32, decode_buckets=[4], **extra))
+    try:
+        pipe.wait_ready(timeout=300)
+        eng = pipe.engine
+        a = [r.wait(180).output for r in [eng.submit(p, greedy(40)) for p in few]]
+        b = [r.wait(300).output for r in [eng.submit(p, greedy(16)) for p in many]]
+        c = [r.wait(180).output for r in [eng.submit(p, greedy(40)) for p in few]]
+        assert eng.wait_idle(30)
+        snap = eng.snapshot()
+    finally:
+        pipe.close()
+    same = lambda x, y: sum(p == q for o1, o2 in zip(x, y) for p, q in zip(o1, o2)) / sum(len(o) for o in x)
+    assert snap["fatal"] is None and snap["failed"] == 0 and snap["kv_blocks_used"] == 0
+    assert all(len(o) == 40 for o in a + c) and all(len(o) == 16 for o in b)
+    assert a == c and same(a, want_few) >= 0.9 and same(b, want_many) >= 0.9
 
 
 def test_a_stage_process_dying_behind_native_rccl_hops_is_answered_and_replaced(monkeypatch):
