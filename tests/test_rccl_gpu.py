@@ -93,7 +93,7 @@ def test_hop_replays_inside_a_captured_graph_with_a_decode_step(edge):
     src = torch.zeros(B, spec.hidden_size, device="cuda", dtype=torch.bfloat16)
     sink = torch.zeros(B, device="cuda", dtype=torch.int32)
     ex.decode_step(d0, hidden[0])                        # uploads the batch composition, warms every kernel
-    st = ex._mbs[0]
+    st = ex._mb_state(0, B)
     st.ctx.zero_(); st.steps.zero_()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
