@@ -35,6 +35,10 @@ def test_config_precedence_yaml_env_flags(tmp_path, monkeypatch):
     assert cfg.partition == "explicit" and cfg.layer_ranges == [(0, 1), (1, 4)]
     with pytest.raises(ValueError):
         EngineConfig.from_dict({"no_such_field": 1})
+    cfg = cli.config_from_args(_args(["--max-batch", "256", "--decode-buckets", "64, 8,512", "--max-queue", "100", "--request-timeout-s", "30"]))
+    assert cfg.decode_buckets == [64, 8, 512] and cfg.graph_sizes() == [8, 64, 256]      # sizes at or above max_batch drop out
+    assert cfg.max_queue == 100 and cfg.request_timeout_s == 30.0
+    assert EngineConfig(max_batch=32).graph_sizes() == [32]
 
 
 def test_plan_command_prints_the_reference_split(capsys):
