@@ -161,6 +161,8 @@ def _coerce(v: str, typ) -> Any:
         return float(v)
     if "List[str]" in t:
         return [s for s in v.split(",") if s]
+    if "List[int]" in t:
+        return [int(s) for s in v.replace("[", "").replace("]", "").split(",") if s.strip()]     # "8,64" or "[8, 64]"
     if "Tuple" in t:
         # "0-11,11-22"
         return [tuple(int(x) for x in part.split("-")) for part in v.split(",") if part]
