@@ -26,7 +26,17 @@ def free_port():
         return s.getsockname()[1]
 
 
-async def soak(url, clients, seconds, max_tokens, seed):
+def tree_rss_mb(pid):
+    """Resident memory of the server process and its stage processes."""
+    import psutil
+    try:
+        root = psutil.Process(pid)
+        return round(sum(p.memory_info().rss for p in [root] + root.children(recursive=True)) / 2**20, 1)
+    except psutil.Error:
+        return None
+
+
+async def soak(url, clients, seconds, max_tokens, seed, server_pid=None):
     import aiohttp
     rng = random.Random(seed)
     stats = {"plain_ok": 0, "stream_ok": 0, "stream_dropped": 0, "gave_up": 0, "failed": 0, "tokens": 0}
@@ -75,7 +85,22 @@ async def soak(url, clients, seconds, max_tokens, seed):
                             stats["failed"] += 1
                 except (aiohttp.ClientError, asyncio.TimeoutError, ConnectionError):
                     stats["failed"] += 1
-        await asyncio.gather(*(client(i) for i in range(clients)))
+        rss = {}
+
+        async def watch_memory():                  # host memory of the server early in the run and at its end
+            await asyncio.sleep(min(20.0, seconds * 0.25))
+            rss["early"] = tree_rss_mb(server_pid)
+            await asyncio.sleep(max(0.0, t_end - time.perf_counter() - 1.0))
+            rss["end"] = tree_rss_mb(server_pid)
+
+        async def progress():                      # a line every 30 s: long runs must not look hung
+            t0 = time.perf_counter()
+            while time.perf_counter() < t_end - 1.0:
+                await asyncio.sleep(min(30.0, max(0.1, t_end - time.perf_counter())))
+                print(f"[{time.perf_counter() - t0:5.0f} s] {json.dumps(stats)}", file=sys.stderr, flush=True)
+
+        await asyncio.gather(*(client(i) for i in range(clients)), progress(), *([watch_memory()] if server_pid else []))
+        stats["server_rss_mb_early"], stats["server_rss_mb_end"] = rss.get("early"), rss.get("end")
         await asyncio.sleep(1.0)
         deadline = time.perf_counter() + 30
         while True:                                             # the scheduler retires cancelled rows at its next recomposition
@@ -124,7 +149,7 @@ def main():
             if proc.poll() is not None or time.time() - t0 > 600:
                 raise SystemExit("the server did not come up")
             time.sleep(0.5)
-        stats, m, idle, after = asyncio.run(soak(url, a.clients, a.seconds, a.max_tokens, a.seed))
+        stats, m, idle, after = asyncio.run(soak(url, a.clients, a.seconds, a.max_tokens, a.seed, proc.pid))
         out = {"seconds": a.seconds, "clients": a.clients, **stats,
                "server": {k[5:]: m.get(k) for k in ("dlia_requests_total", "dlia_requests_completed_total", "dlia_requests_cancelled_total",
                                                     "dlia_requests_failed_total", "dlia_tokens_generated_total", "dlia_requests_running",
