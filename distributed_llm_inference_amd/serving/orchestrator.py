@@ -12,6 +12,7 @@
                        400 {"error":"No prompt provided"}; 500 {"error":"Orchestrator not initialized"};
                        200 {"error":"Error: ...","status":"failed"} on a runtime failure
     GET  /metrics   Prometheus text (addition)
+    GET  /ready     200 {"ready": true, ...} when every stage is online and the engine has not failed, else 503 (addition)
     /v1/models, /v1/completions, /v1/chat/completions   OpenAI-style routes (addition, ASGI server: openai_api.py)
 
 Two backends sit behind the same routes: `EngineBackend` (the pipeline engine: stages over
@@ -366,6 +367,23 @@ class HttpRelayBackend:
         self.session.close()
 
 
+def readiness(backend):
+    """(HTTP status, body) of `GET /ready` — an addition for load balancers and orchestration systems:
+    200 only when every stage is online and the engine has not failed; `/health` keeps the reference's
+    contract (it says "healthy" as long as the process answers, orchestration.py:297-304)."""
+    if backend is None:
+        return 503, {"ready": False, "reason": "not initialized"}
+    try:
+        workers = backend.workers()
+    except Exception as e:
+        return 503, {"ready": False, "reason": f"{type(e).__name__}: {e}"}
+    fatal = getattr(getattr(backend, "engine", None), "fatal", None)
+    down = {k: v for k, v in workers.items() if v != "online"}
+    if fatal or down:
+        return 503, {"ready": False, "reason": fatal or "stages not online", "workers": workers}
+    return 200, {"ready": True, "workers": workers}
+
+
 def sampling_extras(data: Dict) -> Dict:
     """Optional per-request sampling fields of `/generate` (additions: the reference fixes top-k 50 and
     top-p 0.9, orchestration.py:353-354): {"top_k": int >= 0 (0 = off), "top_p": 0 < float <= 1,
@@ -434,6 +452,11 @@ def create_app(backend):
         except (TypeError, ValueError) as e:
             return jsonify({"error": f"max_tokens, temperature, top_k, top_p and seed must be numbers ({e})"}), 400
         return jsonify(b.generate(prompt, max_tokens, temperature, **extra))     # HTTP 200 even when status == failed
+
+    @app.route("/ready", methods=["GET"])
+    def ready():
+        status, body = readiness(app.config["backend"])
+        return jsonify(body), status
 
     @app.route("/metrics", methods=["GET"])
     def metrics():
@@ -524,12 +547,17 @@ def create_asgi_app(backend):
         from starlette.concurrency import run_in_threadpool
         return js(await run_in_threadpool(lambda: b.generate(prompt, max_tokens, temperature, **extra)))
 
+    async def ready(request):
+        from starlette.concurrency import run_in_threadpool
+        status, body = await run_in_threadpool(readiness, state["backend"])     # the HTTP relay asks its workers over HTTP
+        return js(body, status)
+
     async def metrics(request):
         b = state["backend"]
         return PlainTextResponse(b.metrics() if b else "", media_type="text/plain; version=0.0.4", headers=cors)
 
     routes = [Route("/", home), Route("/health", health), Route("/workers", workers),
-              Route("/generate", generate, methods=["POST", "OPTIONS"]), Route("/metrics", metrics)]
+              Route("/generate", generate, methods=["POST", "OPTIONS"]), Route("/metrics", metrics), Route("/ready", ready)]
     from .openai_api import add_routes
     add_routes(routes, state, cors)           # /v1/models, /v1/completions, /v1/chat/completions
     app = Starlette(routes=routes)

@@ -503,6 +503,19 @@ def test_http_relay_reports_dead_worker(http_workers):
         relay.close()
 
 
+def test_ready_route(backend):
+    from starlette.testclient import TestClient
+    from distributed_llm_inference_amd.serving.orchestrator import create_asgi_app
+    with TestClient(create_asgi_app(backend)) as c:
+        r = c.get("/ready")
+        assert r.status_code == 200 and r.json() == {"ready": True, "workers": {"worker_1": "online", "worker_2": "online"}}
+    r = create_app(backend).test_client().get("/ready")
+    assert r.status_code == 200 and r.get_json()["ready"] is True
+    with TestClient(create_asgi_app(None)) as c:
+        assert c.get("/ready").status_code == 503
+    assert create_app(None).test_client().get("/ready").status_code == 503
+
+
 def test_stage_failure_fails_requests_and_shows_in_workers():
     """Kill a stage process mid-generation: in-flight requests get the error envelope within the
     timeout and /workers reports the stage offline (parity with orchestration.py:121-122,220-228)."""
@@ -518,6 +531,9 @@ def test_stage_failure_fails_requests_and_shows_in_workers():
         assert w["worker_1"] == "online" and w["worker_2"] == "offline"
         again = b.generate("Hello", 4, 0.0)               # the engine stays failed, it does not hang
         assert again["status"] == "failed"
+        from distributed_llm_inference_amd.serving.orchestrator import readiness
+        status, body = readiness(b)                       # ... and a load balancer is told so
+        assert status == 503 and body["ready"] is False and body["workers"]["worker_2"] == "offline"
     finally:
         b.close()
 
