@@ -46,7 +46,8 @@ class EngineConfig:
     # Row counts (besides max_batch) for which a micro-batch keeps a captured decode step: with few
     # sequences running, a step covers only the rows up to the highest one in use, rounded up to the
     # next of these, instead of all max_batch rows (a single request on a 256-row micro-batch:
-    # the step of 8 rows instead of 256). [] = every decode step covers max_batch rows.
+    # the step of 8 rows instead of 256). [] = every decode step covers max_batch rows; `serve` on the
+    # HIP backend fills in 8, 64, 512 (those below max_batch) when max_batch >= 128 and none are given.
     decode_buckets: List[int] = field(default_factory=list)
     max_inflight_steps: int = 2            # steps of one micro-batch issued ahead of their results
     # A running micro-batch stops to take waiting requests in (drain, prefill, restart its decode loop)

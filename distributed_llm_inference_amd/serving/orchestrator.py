@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import contextlib
 import itertools
+import os
 import threading
 import time
 from typing import Dict, List
@@ -592,6 +593,10 @@ def serve(cfg: EngineConfig):
             # serving on GPUs: every stage in its own process, none in this one — a stage hung inside a
             # device call can then always be killed and replaced while this process keeps answering
             cfg = dataclasses.replace(cfg, isolate=True)
+        if cfg.resolved_backend() == "hip" and not cfg.decode_buckets and cfg.max_batch >= 128 \
+                and os.environ.get("DLIA_AUTO_DECODE_BUCKETS", "1") != "0":
+            # a server sized for many sequences still answers a lone request at small-batch latency
+            cfg = dataclasses.replace(cfg, decode_buckets=[b for b in (8, 64, 512) if b < cfg.max_batch])
         backend = EngineBackend(make_pipeline(cfg))
         log.info("orchestrator for %s: %d stage(s), backend %s, transport %s", backend.model_name, cfg.pp_size,
                  cfg.resolved_backend(), cfg.resolved_transport())
