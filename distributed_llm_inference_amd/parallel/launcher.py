@@ -66,10 +66,12 @@ def ctrl_slot_bytes(cfg: EngineConfig) -> int:
     (per-row fields of a full micro-batch, a prefill chunk's token ids, the block table of the
     longest admissible prompt for every sequence of a chunk, growth entries), rounded up to a
     power of two. Checked here, at configuration time, not when a descriptor first overflows."""
+    from ..runtime.engine import Engine
     per_seq_blocks = (cfg.max_seq_len + 31) // 32
     chunk = max(cfg.prefill_chunk, cfg.max_batch)
     n = 64 + 40 * cfg.max_batch + 4 * chunk + 4 * (2 * cfg.max_batch + chunk // 32 + per_seq_blocks + cfg.max_batch) \
-        + 12 * cfg.max_batch + 4096
+        + 12 * cfg.max_batch + 4096 \
+        + 4 * Engine.MOVE_BUDGET + 8 * min(cfg.max_batch, Engine.MOVE_BUDGET)      # tables of rows moved at a recomposition
     size = 1 << 16
     while size < n:
         size <<= 1

@@ -73,6 +73,7 @@ class Request:
     error: Optional[str] = None
     done: threading.Event = field(default_factory=threading.Event)
     seed: int = 0
+    moved: bool = False               # its row changed since its block table was last sent to the stages
     callbacks: List = field(default_factory=list)     # called (from the scheduler thread) when the request is done
     token_callbacks: List = field(default_factory=list)   # called (from the scheduler thread) after each output token
 
@@ -174,7 +175,7 @@ class Engine:
         # counters for /metrics
         self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
                       "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0,
-                      "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0, "rejected": 0}
+                      "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0, "rejected": 0, "rows_moved": 0}
         self.latencies: Deque[float] = collections.deque(maxlen=4096)     # per-token decode latencies (s)
         self.ttfts: Deque[float] = collections.deque(maxlen=1024)
 
@@ -405,6 +406,7 @@ class Engine:
             if mb.inflight:
                 return progressed
             self._retire(mb)
+            self._compact(mb)
             if mb.starved:
                 if not self._make_room(mb):
                     return progressed          # other micro-batches hold the pool: wait for them
@@ -461,6 +463,37 @@ class Engine:
         if gone:
             self.stats["recompositions"] += 1
             self._dispatch(control(KIND_RELEASE, gone))
+
+    MOVE_BUDGET = 2048      # block-table entries one recomposition may re-send for moved rows (they ride on one descriptor)
+
+    def _compact(self, mb: _MicroBatch):
+        """With several decode step sizes: move the running rows of a drained micro-batch down into
+        the holes below them when that lets its next steps run at a smaller size — a straggler in row
+        2000 of an otherwise empty micro-batch would keep every step at 2048 rows. A row is a slot of
+        the stages' block table, nothing else: the old slots are released and the next (non-replay)
+        decode step carries the moved requests' tables under their new slots; no KV data moves."""
+        sizes = self._graph_sizes
+        if len(sizes) < 2:
+            return
+        live = [r for r in mb.rows if r is not None]
+        n = len(live)
+        if n == 0 or n == len(mb.rows):
+            return
+        size_of = lambda rows: next((b for b in sizes if b >= rows), len(mb.rows))
+        if size_of(n) >= size_of(max(r.row for r in live) + 1):
+            return                                   # packing them would not reach a smaller step
+        movers = sorted((r for r in live if r.row >= n), key=lambda r: r.row)
+        if sum(len(r.blocks) for r in movers) > self.MOVE_BUDGET:
+            return
+        holes = [i for i in range(n) if mb.rows[i] is None]
+        old = []
+        for r, i in zip(movers, holes):
+            old.append(r.slot)
+            mb.rows[r.row] = None
+            r.row, r.slot, r.moved = i, mb.idx * self.cfg.max_batch + i, True
+            mb.rows[i] = r
+        self.stats["rows_moved"] += len(old)
+        self._dispatch(control(KIND_RELEASE, old))
 
     def _worth_stopping_for(self, mb: _MicroBatch) -> bool:
         """Should this running micro-batch be recomposed to take waiting requests in? Yes when they
@@ -641,6 +674,9 @@ class Engine:
             d.seeds.append(r.seed if live else 0)
             d.sample_steps.append(r.issued_samples if live else 0)
             if live:
+                if r.moved:                      # (only ever set right before a non-replay step)
+                    d.table_slots.append(r.slot); d.table_blocks.append(list(r.blocks))
+                    r.moved = False
                 if not replay:
                     d.token_ids.append(r.output[-1] if r.output else 0)
                 r.issued_ctx += 1

@@ -36,6 +36,7 @@ def render(engine_snapshot: Dict, board=None, num_stages: int = 0) -> str:
     metric("requests_waiting", s.get("waiting"), "requests queued")
     metric("requests_running", s.get("running"), "sequences decoding")
     metric("preemptions_total", s.get("preemptions"), "sequences preempted for KV blocks (recomputed later)", "counter")
+    metric("rows_moved_total", s.get("rows_moved"), "running sequences moved to lower rows so that decode steps could shrink", "counter")
     metric("kv_blocks_grown_total", s.get("kv_blocks_grown"), "KV blocks handed out on demand during decode", "counter")
     metric("kv_blocks_used", s.get("kv_blocks_used"), "KV blocks in use")
     metric("kv_blocks_total", s.get("kv_blocks_total"), "KV blocks per stage")

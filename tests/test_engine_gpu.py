@@ -534,6 +534,40 @@ def test_stage_processes_over_native_rccl_hops_give_the_single_stage_tokens(pp, 
     assert got == ref
 
 
+@pytest.mark.parametrize("pp", [1, 2])
+def test_stragglers_in_high_rows_are_moved_down_so_that_steps_can_shrink(pp):
+    """Two long requests admitted last sit in rows 38 and 39 of a 64-row micro-batch; once the short ones
+    are gone they move to rows 0 and 1 (their block tables re-sent under the new slots, no KV data
+    moved) and the steps shrink from 64 rows to 4. Same tokens as without buckets (up to the
+    split-K rounding of a different row count), across a block boundary after the move."""
+    import time
+    short, long_ = prompts(38, seed=51), prompts(2, seed=52)
+    plain = cfg(pp_size=pp, num_micro_batches=1, max_batch=64)
+    pipe = LocalPipeline(plain)
+    try:
+        reqs = [pipe.engine.submit(p, greedy(6)) for p in short] + [pipe.engine.submit(p, greedy(90)) for p in long_]
+        want = [r.wait(300).output for r in reqs]
+    finally:
+        pipe.close()
+    pipe = LocalPipeline(cfg(pp_size=pp, num_micro_batches=1, max_batch=64, decode_buckets=[4, 16]))
+    try:
+        eng = pipe.engine
+        reqs = [eng.submit(p, greedy(6)) for p in short] + [eng.submit(p, greedy(90)) for p in long_]
+        seen_rows = set()
+        while not all(r.done.is_set() for r in reqs[-2:]):
+            seen_rows.add((reqs[-1].row, eng.mbs[0].nrows))
+            time.sleep(0.0005)
+        got = [r.wait(300).output for r in reqs]
+        assert eng.wait_idle(30)
+        snap = eng.snapshot()
+    finally:
+        pipe.close()
+    assert snap["rows_moved"] == 2 and snap["failed"] == 0 and snap["kv_blocks_used"] == 0
+    assert any(row >= 16 and n == 64 for row, n in seen_rows) and any(row < 4 and n == 4 for row, n in seen_rows), sorted(seen_rows)
+    same = sum(x == y for o1, o2 in zip(got, want) for x, y in zip(o1, o2)) / sum(len(o) for o in want)
+    assert [len(o) for o in got] == [len(o) for o in want] and same >= 0.9, same
+
+
 @pytest.mark.parametrize("shape", ["one stage process, native serving loop", "two stage processes over native RCCL hops"])
 def test_decode_buckets_in_stage_processes(shape, monkeypatch):
     """Decode steps of 4 rows and of 32 rows alternate as the load changes, with the stages in their
