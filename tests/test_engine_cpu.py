@@ -2,6 +2,7 @@
 batches, chunked prefill, continuous batching, EOS / token-cap semantics, and a real
 multi-process 2-stage pipeline over gloo with shared-memory control rings."""
 import threading
+import time
 
 import os
 
@@ -376,3 +377,113 @@ def test_stage_boundaries_inside_layers_keep_the_tokens(model):
             assert run(pipe, ps, greedy(10)) == want, f"pp={pp}"
         finally:
             pipe.close()
+
+
+class _FixedShapeHead:
+    """A stand-in for pipeline stage 0 that behaves like the HIP stages as far as the scheduler can
+    tell: fixed-shape decode steps at the configured sizes (replay descriptors carry no per-row fields,
+    the composition of the last non-replay step is kept), a block table per slot that only changes
+    through the descriptors, padding rows included in the result. The "model": the next token of a
+    row is a function of the FIRST BLOCK of its slot's table and of its position — so a request's
+    tokens do not depend on the row it sits in, and a step over a slot whose table was never sent
+    (or was released) fails loudly."""
+    remote, on_gpu, num_stages = False, False, 1
+
+    def __init__(self, spec, sizes):
+        self.spec, self.sizes = spec, set(sizes)
+        self.tables, self.state, self.steps_by_size = {}, {}, {}
+
+    def graph_decode(self, d):
+        return d.is_decode and d.num_seqs in self.sizes
+
+    def fb_ready(self, mb):
+        return True
+
+    def control(self, d):
+        from distributed_llm_inference_amd.runtime.batch import KIND_RELEASE
+        if d.kind == KIND_RELEASE:
+            for s in d.slots:
+                self.tables.pop(s, None)
+
+    def shutdown(self):
+        pass
+
+    def _tok(self, slot, pos):
+        blocks = self.tables.get(slot)
+        assert blocks, f"step over slot {slot} without a block table"
+        if pos // 32 >= len(blocks):          # a finished or cancelled row riding on as padding: its result is dropped
+            return 0
+        return 3 + (blocks[0] * 7919 + pos * 31) % 200
+
+    def submit(self, d):
+        for s, b in zip(d.table_slots, d.table_blocks):
+            self.tables[s] = list(b)
+        for s, p, b in zip(d.grow_slots, d.grow_pos, d.grow_blocks):
+            assert len(self.tables[s]) == p
+            self.tables[s].append(b)
+        if d.replay:
+            slots, ctx = self.state[d.micro_batch]
+            assert d.num_seqs == len(slots), "a replay step must have the size of its composition"
+        elif self.graph_decode(d):
+            slots = [s if q == 1 else None for s, q in zip(d.slots, d.q_lens)]
+            ctx = list(d.ctx_lens)
+            self.state[d.micro_batch] = (slots, ctx)
+        else:                                               # prefill chunk: one token per sampled sequence
+            toks = [self._tok(s, c + q - 1) for s, q, c, smp in zip(d.slots, d.q_lens, d.ctx_lens, d.sample) if smp and q > 0]
+            return _Done(toks)
+        self.steps_by_size[len(slots)] = self.steps_by_size.get(len(slots), 0) + 1
+        toks = [0 if s is None else self._tok(s, c) for s, c in zip(slots, ctx)]
+        for i, s in enumerate(slots):
+            if s is not None:
+                ctx[i] += 1
+        return _Done(toks)
+
+
+class _Done:
+    def __init__(self, toks):
+        self.toks = toks
+
+    def ready(self):
+        return True
+
+    def get(self):
+        return self.toks
+
+
+def test_scheduler_sizes_decode_steps_to_the_rows_in_use_and_moves_stragglers_down():
+    """The scheduler side of `decode_buckets`, against a stand-in for fixed-shape stages: the step
+    size follows the highest row in use, running rows are packed downwards when that reaches a
+    smaller size (their tables re-sent under the new slots, the old slots released), cancelled and
+    finished rows free their blocks, and every request gets the tokens it gets without buckets."""
+    from distributed_llm_inference_amd.runtime.engine import Engine
+    from distributed_llm_inference_amd.runtime.tokenizer import ByteTokenizer
+    spec = BUILTIN_SPECS["tiny-llama-test"]
+
+    def run_with(buckets):
+        c = cfg(max_batch=32, num_micro_batches=2, max_seq_len=256, decode_buckets=buckets)
+        head = _FixedShapeHead(spec, c.graph_sizes())
+        eng = Engine(c, head, ByteTokenizer(), num_blocks=400).start()
+        try:
+            sp = lambda n: SamplingParams(temperature=0.0, max_new_tokens=n, stop_on_eos=False)
+            short = [eng.submit([5 + i, 6, 7], sp(4)) for i in range(40)]
+            long_ = [eng.submit([9, 9, 9 + i] * 9, sp(70)) for i in range(3)]            # cross block boundaries after the move
+            doomed = eng.submit([4, 4, 4], sp(200))
+            deadline = time.time() + 30
+            while len(doomed.output) < 10 and time.time() < deadline:
+                time.sleep(0.001)
+            eng.cancel(doomed)
+            outs = [r.wait(30).output for r in short + long_]
+            assert eng.wait_idle(10)
+            return outs, eng.snapshot(), head
+        finally:
+            eng.stop()
+
+    want, snap0, head0 = run_with([])
+    got, snap, head = run_with([4, 8])
+    assert got == want and all(len(o) == 70 for o in got[-3:])
+    assert set(head0.steps_by_size) == {32} and snap0["rows_moved"] == 0
+    assert {4, 32} <= set(head.steps_by_size) and snap["rows_moved"] > 0, (head.steps_by_size, snap["rows_moved"])
+    assert head.steps_by_size[4] > head.steps_by_size[32]        # the three long requests ran most of their steps at 4 rows
+    for s in (snap0, snap):
+        assert s["failed"] == 0 and s["cancelled"] == 1 and s["kv_blocks_used"] == 0
+    assert not head.tables and not head0.tables                   # every slot was released in the end
