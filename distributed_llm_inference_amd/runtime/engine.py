@@ -571,7 +571,7 @@ class Engine:
         if r in mb.fresh:
             mb.fresh.remove(r)
         r.context = r.prompt_ids + r.output
-        r.blocks, r.state, r.mb, r.row, r.slot = [], "waiting", -1, -1, -1
+        r.blocks, r.state, r.mb, r.row, r.slot, r.moved = [], "waiting", -1, -1, -1, False
         r.prefilled = r.issued_ctx = 0
         r.issued_samples = len(r.output)
         r.preemptions += 1
