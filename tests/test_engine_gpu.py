@@ -310,6 +310,11 @@ def test_preemption_on_the_gpu_keeps_greedy_tokens():
     got, snap = run(cfg(num_micro_batches=1, kv_blocks=need_all // 2), ps, greedy(90), timeout=300)
     assert snap["preemptions"] > 0 and snap["failed"] == 0
     assert got == want
+    # ... and with decode steps that shrink and rows that move while sequences are preempted and come back
+    got, snap = run(cfg(num_micro_batches=1, kv_blocks=need_all // 2, decode_buckets=[2, 4]), ps, greedy(90), timeout=300)
+    assert snap["preemptions"] > 0 and snap["failed"] == 0 and snap["kv_blocks_used"] == 0
+    same = sum(x == y for o1, o2 in zip(got, want) for x, y in zip(o1, o2)) / sum(len(o) for o in want)
+    assert [len(o) for o in got] == [90] * len(ps) and same >= 0.9, same
 
 
 def test_cancelling_rows_of_a_replaying_micro_batch_leaves_the_other_rows_tokens_unchanged():
