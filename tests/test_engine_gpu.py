@@ -411,15 +411,16 @@ def test_decode_graph_is_captured_once_across_recompositions_on_a_two_stage_pipe
         pipe.close()
 
 
+@pytest.mark.parametrize("mode", [dict(), dict(dtype="fp8", kv_dtype="fp8")], ids=["bf16", "fp8 weights and cache"])
 @pytest.mark.parametrize("pp", [1, 2])
-def test_decode_steps_shrink_to_the_rows_in_use(pp):
+def test_decode_steps_shrink_to_the_rows_in_use(pp, mode):
     """`decode_buckets`: with few sequences running a micro-batch's decode step covers 4 or 16 rows
     instead of all 64 (its own captured graph and static buffers per size), grows back under load,
     and the tokens are those of an engine that always runs 64 rows."""
     few, many = prompts(3, seed=31), prompts(70, seed=32)
-    want_few, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64), few, greedy(20))
-    want_many, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64), many, greedy(12), timeout=300)
-    c = cfg(pp_size=pp, num_micro_batches=2, max_batch=64, decode_buckets=[4, 16, 200])
+    want_few, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64, **mode), few, greedy(20))
+    want_many, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64, **mode), many, greedy(12), timeout=300)
+    c = cfg(pp_size=pp, num_micro_batches=2, max_batch=64, decode_buckets=[4, 16, 200], **mode)
     assert c.graph_sizes() == [4, 16, 64]
     pipe = LocalPipeline(c)
     try:
@@ -439,8 +440,9 @@ def test_decode_steps_shrink_to_the_rows_in_use(pp):
         pipe.close()
     same = lambda a, b: sum(x == y for o1, o2 in zip(a, b) for x, y in zip(o1, o2)) / sum(len(o) for o in a)
     # the kernels pick their split-K by row count, so a 4-row step may round differently from a 64-row one
-    assert same(got_few, want_few) >= 0.9 and same(again, want_few) >= 0.9 and got_few == again
-    assert same(got_many, want_many) >= 0.9
+    floor = 0.9 if not mode else 0.7          # (e4m3 activations: a different row count rounds a few more logits the other way)
+    assert same(got_few, want_few) >= floor and same(again, want_few) >= floor and got_few == again
+    assert same(got_many, want_many) >= floor
     assert snap["failed"] == 0 and snap["fatal"] is None and snap["kv_blocks_used"] == 0
 
 
