@@ -446,3 +446,16 @@ def test_stop_filter_cuts_at_the_first_stop_string_across_piece_boundaries():
     assert "".join([f.feed("abc E"), f.feed("N"), f.feed("x")]) + f.flush() == "abc ENx" and not f.hit
     f = StopFilter(["b", "abc"])
     assert f.feed("xxabc") == "xx" and f.hit             # the earliest hit wins
+
+
+def test_chat_messages_use_the_reference_template_turn_by_turn():
+    """One user message gives the reference's prompt byte for byte (orchestration.py:66); more turns
+    repeat its layout; a system message replaces the default one."""
+    from distributed_llm_inference_amd.runtime.tokenizer import ByteTokenizer, build_chat_prompt, format_chat_prompt
+    tok = ByteTokenizer()
+    default = "You are a helpful assistant."
+    assert build_chat_prompt(tok, [{"role": "user", "content": "Hi"}], default) == format_chat_prompt("Hi", default)
+    got = build_chat_prompt(tok, [{"role": "system", "content": "Be brief."}, {"role": "user", "content": "a"},
+                                  {"role": "assistant", "content": "b"}, {"role": "user", "content": "c"}], default)
+    assert got == "<|system|>\nBe brief.</s>\n<|user|>\na</s>\n<|assistant|>\nb</s>\n<|user|>\nc</s>\n<|assistant|>\n"
+    assert build_chat_prompt(tok, [{"role": "user", "content": "x"}, {"role": "user", "content": "y"}], default, mode="none") == "x\ny"
