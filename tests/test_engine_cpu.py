@@ -418,9 +418,10 @@ class _FixedShapeHead:
     def submit(self, d):
         for s, b in zip(d.table_slots, d.table_blocks):
             self.tables[s] = list(b)
-        for s, p, b in zip(d.grow_slots, d.grow_pos, d.grow_blocks):
-            assert len(self.tables[s]) == p
-            self.tables[s].append(b)
+        for s, p, b in zip(d.grow_slots, d.grow_pos, d.grow_blocks):      # positional, as on the stages: the table of a row
+            t = self.tables.setdefault(s, [])                               # moved in this very descriptor already holds the block
+            assert p <= len(t), f"slot {s}: growth at {p} leaves a gap after {len(t)} blocks"
+            t[p:p + 1] = [b]
         if d.replay:
             slots, ctx = self.state[d.micro_batch]
             assert d.num_seqs == len(slots), "a replay step must have the size of its composition"
