@@ -389,6 +389,7 @@ class SpawnedPipeline:
                         obj.close()
                     except Exception:
                         pass
+                self._sweep_shm()
         self.kv_blocks = min(self.board.read(s)["kv_blocks"] for s in range(world))
         hip = cfg.resolved_backend() == "hip"
         head = RemoteHead(self.spec, world, self.cin, self.res, graph_capable=hip, graph_rows=cfg.graph_sizes(),
@@ -443,6 +444,21 @@ class SpawnedPipeline:
             except Exception:
                 pass
         self.board.close()
+        self._sweep_shm()
+
+    def _sweep_shm(self):
+        """Every shared-memory object of this job carries its unique name prefix. A stage process that was
+        killed, or died, never unlinked the descriptor ring it had created for its successor (tens of
+        megabytes of memory each, held until reboot): once all stage processes are gone the parent removes
+        whatever is left under the prefix."""
+        import glob
+        if any(p.is_alive() for p in self.procs):
+            return
+        for path in glob.glob(f"/dev/shm/{self.job}_*"):
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
 
 
 def attach_distributed(cfg: EngineConfig):
