@@ -324,11 +324,34 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
     return spec, plan, ex, links, board
 
 
+def _exit_with_parent(job: str, poll_s: float = 1.0):
+    """A stage process must not outlive the serving process that started it: were that one killed
+    outright (out of memory, `kill -9`) its stages would keep their GPUs and spin on rings nobody
+    feeds. A daemon thread watches the parent pid; when it changes it removes the job's shared-memory
+    objects (nobody else will) and ends this process."""
+    import threading
+    parent = os.getppid()
+
+    def watch():
+        while os.getppid() == parent:
+            time.sleep(poll_s)
+        import glob
+        for path in glob.glob(f"/dev/shm/{job}_*"):       # the parent can no longer sweep; mappings stay valid for siblings
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        os._exit(1)
+
+    threading.Thread(target=watch, name="dlia-parent-watch", daemon=True).start()
+
+
 def _stage_entry(cfg_dict: dict, rank: int, world: int, job: str, master_port: int):
     """Body of one spawned stage process: stage 0 serves the scheduler's descriptor ring
     (`head_main`), every other stage the ring of its predecessor (`stage_main`)."""
     from ..runtime.head import head_main
     from .transport import ShmControl
+    _exit_with_parent(job)
     cfg = EngineConfig.from_dict(cfg_dict)
     spec, plan, ex, links, board = stage_process_setup(cfg, rank, world, job, master_port, create_board=False)
     rt = StageRuntime(ex, links, board=board, fault=cfg.fault_inject, tracer=make_tracer(cfg.trace_path),

@@ -488,3 +488,40 @@ def test_scheduler_sizes_decode_steps_to_the_rows_in_use_and_moves_stragglers_do
     for s in (snap0, snap):
         assert s["failed"] == 0 and s["cancelled"] <= 1 and s["kv_blocks_used"] == 0     # (the stand-in may finish it first)
     assert not head.tables and not head0.tables                   # every slot was released in the end
+
+
+def test_stage_processes_end_when_their_serving_process_is_killed(tmp_path):
+    """`kill -9` of the process that spawned a pipeline: its stage processes notice within seconds
+    and exit instead of lingering with their devices."""
+    import subprocess
+    import sys
+    import psutil
+    script = (
+        "import os, sys, time\n"
+        "from distributed_llm_inference_amd.config import EngineConfig\n"
+        "from distributed_llm_inference_amd.parallel.launcher import make_pipeline\n"
+        "if __name__ == '__main__':\n"
+        "    pipe = make_pipeline(EngineConfig(model='tiny-llama-test', pp_size=2, max_batch=4, num_micro_batches=2, max_seq_len=64,\n"
+        "                                      backend='torch', device='cpu', transport='gloo', partition='even'))\n"
+        "    print('PIDS ' + ' '.join(str(p.pid) for p in pipe.procs), flush=True)\n"
+        "    time.sleep(2)\n"
+        "    os.kill(os.getpid(), 9)\n")
+    path = tmp_path / "orphan.py"
+    path.write_text(script)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.Popen([sys.executable, str(path)], stdout=subprocess.PIPE, cwd=root, text=True,
+                         env={**os.environ, "PYTHONPATH": root})
+    line = ""
+    while not line.startswith("PIDS "):                       # (gloo prints its own lines to stdout)
+        line = p.stdout.readline()
+        assert line, "the spawning process ended without reporting its stage processes"
+    pids = [int(x) for x in line.split()[1:]]
+    assert len(pids) == 2 and all(psutil.pid_exists(x) for x in pids)
+    p.wait(60)
+    deadline = time.time() + 20
+    while time.time() < deadline and any(psutil.pid_exists(x) and psutil.Process(x).status() != psutil.STATUS_ZOMBIE for x in pids):
+        time.sleep(0.2)
+    left = [x for x in pids if psutil.pid_exists(x) and psutil.Process(x).status() != psutil.STATUS_ZOMBIE]
+    assert not left, left
+    import glob
+    assert not glob.glob("/dev/shm/dlia_%d_*" % p.pid)         # ... and took the job's shared memory with them
