@@ -600,6 +600,18 @@ def serve(cfg: EngineConfig):
         backend = EngineBackend(make_pipeline(cfg))
         log.info("orchestrator for %s: %d stage(s), backend %s, transport %s", backend.model_name, cfg.pp_size,
                  cfg.resolved_backend(), cfg.resolved_transport())
+    import signal
+
+    def on_term(signum, frame):
+        raise SystemExit(0)
+
+    # uvicorn shuts down on SIGTERM and then raises the signal again for whoever handled it before:
+    # with the default action the process would end right there, before the `finally` below has closed
+    # the pipeline (stage processes, shared memory). With this handler it unwinds through it.
+    try:
+        signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                      # not the main thread (a test driving serve() from a thread)
+        pass
     try:
         if cfg.server == "flask":
             create_app(backend).run(host=cfg.host, port=cfg.port, debug=False, threaded=True)
