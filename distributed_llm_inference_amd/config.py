@@ -72,6 +72,7 @@ class EngineConfig:
     server: str = "uvicorn"                # HTTP server of `serve`: "uvicorn" (ASGI) | "flask" (Werkzeug dev server, as the reference)
     worker_urls: List[str] = field(default_factory=list)   # http transport: one URL per worker
     request_timeout_s: float = 200.0       # Test.py:71
+    shutdown_grace_s: float = 30.0         # SIGTERM: requests still open after this long are cancelled and the server leaves
     max_queue: int = 0                     # requests allowed to wait for a row; 0 = unbounded. Beyond it a request fails at once ("queue full")
     stream_cost_ms: float = 0.25           # streaming: a stream sends at most one event per (open streams x this)
     hop_timeout_s: float = 30.0            # orchestration.py:118

@@ -618,6 +618,7 @@ def serve(cfg: EngineConfig):
         else:
             import uvicorn
             uvicorn.run(create_asgi_app(backend), host=cfg.host, port=cfg.port, log_level="warning",
-                        timeout_keep_alive=30, backlog=4096)
+                        timeout_keep_alive=30, backlog=4096,
+                        timeout_graceful_shutdown=int(cfg.shutdown_grace_s))   # then open requests are cancelled
     finally:
         backend.close()
