@@ -49,6 +49,7 @@ class EngineConfig:
     # the step of 8 rows instead of 256). [] = every decode step covers max_batch rows; `serve` on the
     # HIP backend fills in 8, 64, 512 (those below max_batch) when max_batch >= 128 and none are given.
     decode_buckets: List[int] = field(default_factory=list)
+    warm_decode_graphs: bool = True        # with decode_buckets: allocate and capture every (micro-batch, size) step at bring-up rather than at first use
     max_inflight_steps: int = 2            # steps of one micro-batch issued ahead of their results
     # A running micro-batch stops to take waiting requests in (drain, prefill, restart its decode loop)
     # only when that fills at least this share of its rows, or the oldest waiter has waited this long:

@@ -18,6 +18,7 @@ Same interface as `RefStage`; what it replaces in the reference is `Worker.proce
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -32,8 +33,7 @@ from .spec import ModelSpec
 from .weights import StageWeights
 
 BLOCK = packing.KV_BLOCK
-import os as _os
-DECODE_ROWS = int(_os.environ.get('DLIA_DECODE_ROWS', '256'))      # row count up to which GEMMs take the weight-streaming kernel (with split-K partials)
+DEFAULT_DECODE_ROWS = 256      # row count up to which GEMMs take the weight-streaming kernel (with split-K partials)
 
 
 @dataclass
@@ -71,7 +71,8 @@ class _MicroBatchState:
     steps: torch.Tensor          # int32 [B] RNG counters; advanced in-graph
     wk: Optional[_Work] = None
     graph: Optional[torch.cuda.CUDAGraph] = None
-    splits: int = 1
+    splits: int = 1              # split-KV factor the captured step was built with
+    splits_wanted: int = 1       # split-KV factor the current composition calls for (re-capture when it differs)
 
 
 class GpuStage:
@@ -81,12 +82,14 @@ class GpuStage:
                  max_slots: int = 256, max_seq_len: int = 2048, num_blocks: Optional[int] = None,
                  max_tokens: int = 2048, max_batch: int = 64, use_graphs: bool = True,
                  kv_mem_fraction: float = 0.85, weight_dtype: str = "bf16", kv_dtype: str = "bf16",
-                 decode_states: int = 1, defer_kv: bool = False, graph_sizes: Optional[List[int]] = None):
+                 decode_states: int = 1, defer_kv: bool = False, graph_sizes: Optional[List[int]] = None,
+                 decode_rows: Optional[int] = None):
         """`num_blocks`: KV blocks of this stage's cache; None sizes it from the device memory that is
         free once weights and workspaces are resident (`kv_mem_fraction` of it, less what the
         `decode_states` micro-batch workspaces will take). `defer_kv`: do not allocate the cache
         yet — the caller reads `kv_budget_blocks()`, agrees on one count with the other stages and
-        calls `allocate_kv()`."""
+        calls `allocate_kv()`. `decode_rows`: steps of up to this many tokens run the weight-streaming
+        GEMMs (default 256, or DLIA_DECODE_ROWS from the environment of the process building the stage)."""
         if not torch.cuda.is_available():
             raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
         if spec.head_dim not in (64, 128):
@@ -96,6 +99,7 @@ class GpuStage:
         if kv_dtype not in ("bf16", "fp8"):
             raise ValueError("kv_dtype must be bf16 or fp8")
         self.kv8 = kv_dtype == "fp8"
+        self.decode_rows = int(decode_rows if decode_rows is not None else os.environ.get("DLIA_DECODE_ROWS", DEFAULT_DECODE_ROWS))
         self.K = ops.load()
         # decoder-layer GEMMs: "fp8" = e4m3 weights (per-channel scale) x e4m3 activations (per-row
         # dynamic scale) on the block-scaled fp8 MFMA; "fp8w" = e4m3 weights widened to bf16 in
@@ -160,7 +164,7 @@ class GpuStage:
         for (n_, k_, e_) in ((spec.qkv_size, H, 6), (H, spec.q_size, 6), (H, I, 6),
                              (2 * I if spec.is_llama else I, H, 4 if spec.is_llama else 5),
                              (packing.padded_n(V), H, 0)):
-            for m_ in range(1, DECODE_ROWS + 1):    # any token count up to this takes the weight-streaming path
+            for m_ in range(1, self.decode_rows + 1):    # any token count up to this takes the weight-streaming path
                 sk = int(self.K.gemm_config(m_, n_, k_, e_, True)[1])
                 if e_ == 6 or sk > 1:               # direct epilogues of an unsplit GEMM need no partials
                     need = max(need, sk * m_ * n_)
@@ -184,6 +188,7 @@ class GpuStage:
         self._mbs: Dict[tuple, _MicroBatchState] = {}      # (micro-batch, rows) -> static decode state
         self._gemm_cfg: Dict[tuple, tuple] = {}
         self._ones = torch.ones(H, device=dev, dtype=bf)
+        self._arange = torch.arange(max_batch + 1, device=dev, dtype=torch.int32)      # q_start of a decode step: one token per row
         self.scale = 1.0 / math.sqrt(spec.head_dim)
         self.graph_replays = 0
         self.graph_captures = 0
@@ -192,13 +197,13 @@ class GpuStage:
         s, dev, bf = self.spec, self.device, torch.bfloat16
         z = lambda *shape, dt=bf: torch.zeros(*shape, device=dev, dtype=dt)
         B = min(rows, self.max_batch)            # sequences (sampled rows) a step over this workspace can have
-        # GEMM workspace: split-K partials of the weight-streaming kernels (up to DECODE_ROWS rows) in
+        # GEMM workspace: split-K partials of the weight-streaming kernels (up to `decode_rows` rows) in
         # front, or the slabs of the large-M kernel's in-launch split-K; the last 4096 words are that
         # kernel's arrival counters and must stay zero between launches (nobody else writes there)
         ws_floats = self._ws_floats
         if self.wmode in ("bf16", "fp8"):        # (the e4m3 kernel splits at most as far as the bf16 one)
             for m_ in {rows, min(rows, 512), min(rows, 1024)}:
-                if m_ > DECODE_ROWS:
+                if m_ > self.decode_rows:
                     ws_floats = max([ws_floats] + [int(self.K.gemm_ws_floats(m_, n_, k_)) for n_, k_ in self._gemm_shapes])
         return _Work(
             h=z(rows, s.hidden_size), xn=z(rows, s.hidden_size), qkv=z(rows, s.qkv_size), attn=z(rows, s.q_size),
@@ -356,7 +361,7 @@ class GpuStage:
             K.norm(xn, h, None, part, S, pbias, w, b, None, s.norm_eps, nmode)
             return xn
 
-        if T > DECODE_ROWS:
+        if T > self.decode_rows:
             # compute-bound regime (large decode micro-batches, prefill chunks): tiled MFMA GEMMs with
             # fused bias / residual / activation epilogues; the 256 x 256 kernel (bf16 and e4m3) splits
             # K inside the launch on shapes with fewer tiles than CUs and needs the workspace for that
@@ -549,8 +554,6 @@ class GpuStage:
         B = batch.num_seqs
         if B > self.max_batch:
             raise ValueError(f"micro-batch of {B} exceeds max_batch {self.max_batch}")
-        if not hasattr(self, "_arange"):
-            self._arange = torch.arange(self.max_batch + 1, device=self.device, dtype=torch.int32)
         st = self._mb_state(batch.micro_batch, B)
         self.apply_growth(batch)
         if not batch.replay:
@@ -573,12 +576,11 @@ class GpuStage:
         if x is not None:
             (st.ids if self.plan.has_embed else st.hidden_in).copy_(x)
         if not self.use_graphs:
-            st.splits = getattr(st, "splits_wanted", 1)
+            st.splits = st.splits_wanted
             self._decode_body(st)
         else:
-            want = getattr(st, "splits_wanted", 1)
-            if st.graph is None or st.splits != want:
-                st.splits = want
+            if st.graph is None or st.splits != st.splits_wanted:
+                st.splits = st.splits_wanted
                 self._capture(st)
             st.graph.replay()
             self.graph_replays += 1
@@ -591,8 +593,6 @@ class GpuStage:
         and a graph capture (measured: 2.6 s of a 512-client burst). One size only: left to first use."""
         if not self.use_graphs or len(self.graph_sizes) < 2 or self.kv is None:
             return
-        if not hasattr(self, "_arange"):
-            self._arange = torch.arange(self.max_batch + 1, device=self.device, dtype=torch.int32)
         for mb in range(self.decode_states):
             for B in self.graph_sizes:
                 st = self._mb_state(mb, B)

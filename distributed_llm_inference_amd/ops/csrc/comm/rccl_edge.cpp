@@ -72,7 +72,9 @@ int fail(const char* what, const char* detail, int code) {
     if (r_ != 0) return fail(#expr, g_api.GetErrorString ? g_api.GetErrorString(r_) : "rccl", (int)r_); \
   } while (0)
 
-constexpr int kSlots = 256;            // completion events in flight per edge (a ring)
+constexpr int kSlots = 256;            // completion events in flight per edge (a ring; power of two)
+constexpr uint32_t kTokenMask = 0x3FFFFFFFu;   // tokens are transfer sequence numbers modulo 2^30
+constexpr int kRingWaitMs = 30000;     // longest a new transfer waits for the one 256 transfers earlier
 
 struct Edge {
   ncclComm_t comm = nullptr;
@@ -80,9 +82,10 @@ struct Edge {
   hipStream_t stream = nullptr;
   hipEvent_t done[kSlots];
   hipEvent_t fence[kSlots];
-  uint32_t next = 0;
+  bool used[kSlots] = {};
+  uint32_t next = 0;                   // sequence number of the next transfer (modulo 2^30)
   std::atomic<int> aborted{0};
-  uint64_t bytes_sent = 0, bytes_recv = 0, ops = 0;
+  uint64_t bytes_sent = 0, bytes_recv = 0, ops = 0, ring_waits = 0;
 };
 
 struct DeviceScope {                   // HIP's current device is per thread; leave it as found
@@ -93,7 +96,38 @@ struct DeviceScope {                   // HIP's current device is per thread; le
   ~DeviceScope() { if (changed) hipSetDevice(prev); }
 };
 
-int take_slot(Edge* e) { int s = (int)(e->next % kSlots); e->next++; return s; }
+// A completion token is the transfer's sequence number; its events live in slot token % kSlots. The
+// slot of transfer t is reused by transfer t + kSlots, and re-recording an event somebody still
+// waits for would make that waiter observe the NEWER transfer: a new transfer therefore takes its
+// slot only once the transfer that last used it has completed (the host polls with a deadline; with
+// the few micro-batches a pipeline keeps in flight it never has to). A token more than kSlots
+// transfers old names a transfer that has therefore completed: waiting for it is a no-op.
+int slot_of(int token) { return (int)((uint32_t)token % kSlots); }
+
+bool token_expired(const Edge* e, int token) {
+  return ((e->next - (uint32_t)token) & kTokenMask) > (uint32_t)kSlots;
+}
+
+int take_token(Edge* e) {
+  const uint32_t t = e->next & kTokenMask;
+  const int s = (int)(t % kSlots);
+  if (e->used[s]) {
+    auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      hipError_t q = hipEventQuery(e->done[s]);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return fail("hipEventQuery", hipGetErrorString(q), (int)q);
+      if (e->aborted.load()) return fail("completion ring", "edge aborted", 0);
+      if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > kRingWaitMs)
+        return fail("completion ring", "256 transfers in flight and the oldest does not complete", 0);
+      e->ring_waits++;
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+  }
+  e->used[s] = true;
+  e->next = (e->next + 1) & kTokenMask;
+  return (int)t;
+}
 
 // `after_stream` is a stream handle, where null IS a stream (the default one); "no stream" is
 // DLIA_NO_STREAM.
@@ -183,24 +217,28 @@ int dlia_edge_send(void* h, const void* ptr, size_t nbytes, void* after_stream) 
   Edge* e = static_cast<Edge*>(h);
   if (e->aborted.load()) return fail("dlia_edge_send", "edge aborted", 0);
   DeviceScope ds(e->device);
-  int slot = take_slot(e);
+  const int token = take_token(e);
+  if (token < 0) return -1;
+  const int slot = slot_of(token);
   if (fence_from(e, slot, after_stream, nullptr)) return -1;
   NCCLCHK(g_api.Send(ptr, nbytes, kNcclInt8, e->peer, e->comm, e->stream));
   HIPCHK(hipEventRecord(e->done[slot], e->stream));
   e->bytes_sent += nbytes; e->ops++;
-  return slot;
+  return token;
 }
 
 int dlia_edge_recv(void* h, void* ptr, size_t nbytes, void* after_stream, void* after_event) {
   Edge* e = static_cast<Edge*>(h);
   if (e->aborted.load()) return fail("dlia_edge_recv", "edge aborted", 0);
   DeviceScope ds(e->device);
-  int slot = take_slot(e);
+  const int token = take_token(e);
+  if (token < 0) return -1;
+  const int slot = slot_of(token);
   if (fence_from(e, slot, after_stream, (hipEvent_t)after_event)) return -1;
   NCCLCHK(g_api.Recv(ptr, nbytes, kNcclInt8, e->peer, e->comm, e->stream));
   HIPCHK(hipEventRecord(e->done[slot], e->stream));
   e->bytes_recv += nbytes; e->ops++;
-  return slot;
+  return token;
 }
 
 // Send and receive with the peer as one group (a rank exchanging with itself on a one-rank
@@ -209,7 +247,9 @@ int dlia_edge_sendrecv(void* h, const void* sptr, void* rptr, size_t nbytes, voi
   Edge* e = static_cast<Edge*>(h);
   if (e->aborted.load()) return fail("dlia_edge_sendrecv", "edge aborted", 0);
   DeviceScope ds(e->device);
-  int slot = take_slot(e);
+  const int token = take_token(e);
+  if (token < 0) return -1;
+  const int slot = slot_of(token);
   if (fence_from(e, slot, after_stream, nullptr)) return -1;
   NCCLCHK(g_api.GroupStart());
   ncclResult_t r1 = g_api.Send(sptr, nbytes, kNcclInt8, e->peer, e->comm, e->stream);
@@ -218,7 +258,7 @@ int dlia_edge_sendrecv(void* h, const void* sptr, void* rptr, size_t nbytes, voi
   if (r1 || r2 || r3) return fail("grouped send/recv", g_api.GetErrorString(r1 ? r1 : (r2 ? r2 : r3)), r1 ? r1 : (r2 ? r2 : r3));
   HIPCHK(hipEventRecord(e->done[slot], e->stream));
   e->bytes_sent += nbytes; e->bytes_recv += nbytes; e->ops++;
-  return slot;
+  return token;
 }
 
 // ---- the same transfers on the caller's stream (capturable into a hipGraph) --------------------
@@ -254,16 +294,18 @@ int dlia_edge_sendrecv_on(void* h, const void* sptr, void* rptr, size_t nbytes, 
 // Make `stream` wait for the transfer behind `token` (no host blocking).
 int dlia_edge_wait(void* h, int token, void* stream) {
   Edge* e = static_cast<Edge*>(h);
-  if (token < 0 || token >= kSlots) return fail("dlia_edge_wait", "bad token", token);
-  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->done[token], 0));
+  if (token < 0 || (uint32_t)token > kTokenMask) return fail("dlia_edge_wait", "bad token", token);
+  if (token_expired(e, token)) return 0;              // completed long ago (its slot has been reused since)
+  HIPCHK(hipStreamWaitEvent((hipStream_t)stream, e->done[slot_of(token)], 0));
   return 0;
 }
 
 // 1 = complete, 0 = still in flight, -1 = the communicator reported an asynchronous error.
 int dlia_edge_query(void* h, int token) {
   Edge* e = static_cast<Edge*>(h);
-  if (token < 0 || token >= kSlots) return fail("dlia_edge_query", "bad token", token);
-  hipError_t q = hipEventQuery(e->done[token]);
+  if (token < 0 || (uint32_t)token > kTokenMask) return fail("dlia_edge_query", "bad token", token);
+  if (token_expired(e, token)) return 1;
+  hipError_t q = hipEventQuery(e->done[slot_of(token)]);
   if (q == hipSuccess) return 1;
   if (q != hipErrorNotReady) return fail("hipEventQuery", hipGetErrorString(q), (int)q);
   if (e->aborted.load()) return fail("dlia_edge_query", "edge aborted", 0);
@@ -290,9 +332,9 @@ int dlia_edge_sync(void* h, int token, int timeout_ms) {
 
 void* dlia_edge_stream(void* h) { return static_cast<Edge*>(h)->stream; }
 
-void dlia_edge_stats(void* h, uint64_t* out3) {
+void dlia_edge_stats(void* h, uint64_t* out4) {
   Edge* e = static_cast<Edge*>(h);
-  out3[0] = e->bytes_sent; out3[1] = e->bytes_recv; out3[2] = e->ops;
+  out4[0] = e->bytes_sent; out4[1] = e->bytes_recv; out4[2] = e->ops; out4[3] = e->ring_waits;
 }
 
 // Tear the communicator down without waiting for its outstanding transfers: kernels spinning on a

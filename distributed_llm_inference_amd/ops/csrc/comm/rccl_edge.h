@@ -22,7 +22,7 @@ int dlia_edge_wait(void* edge, int token, void* stream);
 int dlia_edge_query(void* edge, int token);
 int dlia_edge_sync(void* edge, int token, int timeout_ms);
 void* dlia_edge_stream(void* edge);
-void dlia_edge_stats(void* edge, uint64_t* out3);
+void dlia_edge_stats(void* edge, uint64_t* out4);
 int dlia_edge_abort(void* edge);
 int dlia_edge_close(void* edge);
 }

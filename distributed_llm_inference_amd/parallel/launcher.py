@@ -116,10 +116,10 @@ def kv_budget(cfg: EngineConfig, ex, share: float = 1.0) -> int:
     return ex.kv_budget_blocks(share)
 
 
-def settle_kv(ex, blocks: int):
+def settle_kv(ex, blocks: int, warm: bool = True):
     if hasattr(ex, "allocate_kv") and ex.kv is None:
         ex.allocate_kv(blocks)
-    if hasattr(ex, "warm_decode_states"):
+    if warm and hasattr(ex, "warm_decode_states"):
         ex.warm_decode_states()          # with decode buckets: every size's state and graph exist before the first request
 
 
@@ -144,12 +144,13 @@ class LocalPipeline:
         on_gpu = dev is not None and torch.device(dev).type == "cuda" and hasattr(exs[0], "decode_step")
         act_bytes = 2 * self.spec.hidden_size * max(cfg.prefill_chunk, cfg.max_batch)
         links = make_loopback_links(cfg.pp_size, device=dev if on_gpu else None, max_bytes=act_bytes,
-                                    fb_bytes=4 * max(cfg.max_batch, 64), job=self.job, ctrl_slot_bytes=ctrl_slot_bytes(cfg))
+                                    fb_bytes=4 * max(cfg.max_batch, 64), job=self.job, ctrl_slot_bytes=ctrl_slot_bytes(cfg),
+                                    timeout_s=cfg.hop_timeout_s * cfg.pp_size)
         # every stage's cache holds the same number of blocks: the smallest budget (the stages of an
         # in-process pipeline split one device between them)
         self.kv_blocks = min(kv_budget(cfg, ex, 1.0 / len(exs)) for ex in exs)
         for ex in exs:
-            settle_kv(ex, self.kv_blocks)
+            settle_kv(ex, self.kv_blocks, cfg.warm_decode_graphs)
         self.executors = exs
         self.tracer = make_tracer(cfg.trace_path)      # one process: all stages share the tracer
         self.runtimes = [StageRuntime(ex, l, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
@@ -309,7 +310,7 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
                 limit_p2p_channels()             # before any RCCL communicator exists (also the rccl-torch fallback's)
             init_distributed(rank, world, backend, master_port, device if dev_kind == "cuda" else None)
         ex = build_executor(cfg, spec, plan, device=device, defer_kv=True)
-        settle_kv(ex, board.agree_kv_blocks(rank, kv_budget(cfg, ex, share)))
+        settle_kv(ex, board.agree_kv_blocks(rank, kv_budget(cfg, ex, share)), cfg.warm_decode_graphs)
         slot = ctrl_slot_bytes(cfg)
         if world == 1:
             links = make_loopback_links(1)[0]
@@ -322,6 +323,36 @@ def stage_process_setup(cfg: EngineConfig, rank: int, world: int, job: str, mast
         board.set_state(rank, ST_ERROR, f"{type(e).__name__}: {e}")
         raise
     return spec, plan, ex, links, board
+
+
+def open_links_only(cfg: EngineConfig, rank: int, world: int):
+    """The default group and this rank's pipeline hops, without a model or a KV cache: what a
+    pre-flight check of a node opens, times and closes (`bench.py --preflight`). Reads MASTER_PORT /
+    LOCAL_RANK like `attach_distributed`. Returns (links, device or None on CPU)."""
+    dev_kind = cfg.resolved_device()
+    transport = cfg.resolved_transport()
+    backend = _group_backend(transport)
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    job = f"dlia_pf_{port}_{os.getppid()}"
+    device = None
+    if dev_kind == "cuda":
+        idx = int(os.environ.get("LOCAL_RANK", str(rank)))
+        ndev = torch.cuda.device_count()
+        if world > ndev > 0 and (transport == "gloo" or os.environ.get("DLIA_SHARE_GPU") == "1"):
+            idx %= ndev
+            if transport != "gloo" and os.environ.get("DLIA_RCCL_DISTINCT_HOSTS") == "1":
+                os.environ["NCCL_HOSTID"] = f"dlia-rehearsal-rank-{rank}"
+        device = f"cuda:{idx}"
+        torch.cuda.set_device(torch.device(device))
+        from .rccl import limit_p2p_channels
+        limit_p2p_channels()
+    init_distributed(rank, world, backend, port, device)
+    if transport == "rccl" and dev_kind == "cuda":
+        links = rccl_links_or_fallback(rank, world, job, device, 1 << 16)
+    else:
+        links = make_dist_links(rank, world, backend, job, host_staged=(dev_kind == "cuda" and backend == "gloo"),
+                                ctrl_slot_bytes=1 << 16)
+    return links, device
 
 
 def _exit_with_parent(job: str, poll_s: float = 1.0):
@@ -401,18 +432,21 @@ class SpawnedPipeline:
                 self.wait_ready(ready_timeout)
                 break
             except BaseException as e:
+                # A failed bring-up leaves nothing behind: the caller gets no object to close, so the stage
+                # processes are killed and every shared-memory object of this attempt (scheduler rings,
+                # status board, the rings the stages created for their successors) is removed here.
                 self.kill()
-                # The rendezvous port was free when picked, but another socket of this machine may take it
-                # before rank 0 listens on it: that attempt is discarded whole and made again on a new port.
-                clash = isinstance(e, RuntimeError) and ("failed to listen" in str(e) or "ddress already in use" in str(e))
-                if not clash or attempt == 2:
-                    raise
                 for obj in (self.cin, self.res, self.board):
                     try:
                         obj.close()
                     except Exception:
                         pass
                 self._sweep_shm()
+                # The rendezvous port was free when picked, but another socket of this machine may take it
+                # before rank 0 listens on it: that attempt is discarded whole and made again on a new port.
+                clash = isinstance(e, RuntimeError) and ("failed to listen" in str(e) or "ddress already in use" in str(e))
+                if not clash or attempt == 2:
+                    raise
         self.kv_blocks = min(self.board.read(s)["kv_blocks"] for s in range(world))
         hip = cfg.resolved_backend() == "hip"
         head = RemoteHead(self.spec, world, self.cin, self.res, graph_capable=hip, graph_rows=cfg.graph_sizes(),

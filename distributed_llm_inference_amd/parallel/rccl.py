@@ -185,9 +185,9 @@ class RcclEdge(Edge):
 
     # ---- lifecycle ---------------------------------------------------------------------------
     def stats(self):
-        out = (C.c_uint64 * 3)()
+        out = (C.c_uint64 * 4)()
         self.L.dlia_edge_stats(self.h, out)
-        return {"bytes_sent": int(out[0]), "bytes_recv": int(out[1]), "ops": int(out[2])}
+        return {"bytes_sent": int(out[0]), "bytes_recv": int(out[1]), "ops": int(out[2]), "ring_waits": int(out[3])}
 
     def abort(self):
         """Release transfers stuck on a peer that will never answer; only `close` is valid after."""

@@ -311,18 +311,20 @@ class PipelineLinks:
 
 
 def make_loopback_links(num_stages: int, device=None, max_bytes: int = 0, fb_bytes: int = 0, job: Optional[str] = None,
-                        ctrl_slot_bytes: int = 1 << 17) -> List[PipelineLinks]:
+                        ctrl_slot_bytes: int = 1 << 17, timeout_s: float = 60.0) -> List[PipelineLinks]:
     """Links of an in-process pipeline. With a GPU `device` (and a `job` name for the rings) the hops
     are native device hops (`LocalDeviceEdge`: staging ring + events, `max_bytes` per hidden-state
     message, `fb_bytes` per token message) and the descriptors travel over shared-memory rings —
-    the pieces the native stage loop is built on; otherwise in-process queues."""
+    the pieces the native stage loop is built on; otherwise in-process queues. `timeout_s`: how long
+    a device hop's receive waits for its sender to have enqueued the message (a dead stage thread
+    surfaces after this long)."""
     links = [PipelineLinks(s, num_stages) for s in range(num_stages)]
     native = device is not None and torch.device(device).type == "cuda" and job is not None and num_stages > 1
     if native:
         from .local_edge import LocalDeviceEdge
     for s in range(num_stages - 1):
         if native:
-            e = LocalDeviceEdge(device, max_bytes, name=f"{s}->{s + 1}")
+            e = LocalDeviceEdge(device, max_bytes, timeout_s=timeout_s, name=f"{s}->{s + 1}")
             cp = ShmControl(f"{job}_c{s}", create=True, slot_bytes=ctrl_slot_bytes)
             cc = ShmControl(f"{job}_c{s}", create=False, slot_bytes=ctrl_slot_bytes)
             links[s].next_ctrl, links[s + 1].prev_ctrl = cp, cc
@@ -331,7 +333,7 @@ def make_loopback_links(num_stages: int, device=None, max_bytes: int = 0, fb_byt
             links[s].next_ctrl, links[s + 1].prev_ctrl = c, c
         links[s].next_data, links[s + 1].prev_data = e, e
     if num_stages > 1:
-        fb = LocalDeviceEdge(device, max(fb_bytes, 256), name=f"{num_stages - 1}->0 (tokens)") if native else LoopbackEdge()
+        fb = LocalDeviceEdge(device, max(fb_bytes, 256), timeout_s=timeout_s, name=f"{num_stages - 1}->0 (tokens)") if native else LoopbackEdge()
         links[0].fb_data = links[-1].fb_data = fb
         if native:
             for l in links:

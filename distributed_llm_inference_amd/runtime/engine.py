@@ -297,7 +297,9 @@ class Engine:
             while not self._stop:
                 progressed = False
                 while self._inbox:
-                    self.waiting.append(self._inbox.popleft())
+                    req = self._inbox.popleft()
+                    if not req.finished:            # cancelled between submit() and this tick: never queued
+                        self.waiting.append(req)
                     progressed = True
                 while self._cancel_box:
                     self._cancel(self._cancel_box.popleft())
@@ -358,7 +360,7 @@ class Engine:
         if req.finished:
             return
         if req.state == "waiting":
-            try:
+            try:                           # (a request still in the inbox is dropped when the inbox is drained)
                 self.waiting.remove(req)
             except ValueError:
                 pass
@@ -519,6 +521,9 @@ class Engine:
     def _admit(self, mb: _MicroBatch):
         while self.waiting and mb.free_rows() > 0:
             req = self.waiting[0]
+            if req.finished:               # cancelled while queued: takes no row and no blocks
+                self.waiting.popleft()
+                continue
             need = max(1, blocks_for(len(req.context)))
             if need > self.max_blocks_per_seq or need > self.alloc.num_blocks:
                 self.waiting.popleft()

@@ -63,7 +63,9 @@ class _EventHandle(Handle):
 
 
 class LocalHead:
-    """Stage 0 in this process."""
+    """Stage 0 in this process. Over RCCL hops nothing here blocks the host. Over the in-process device
+    hops of a single-process GPU pipeline (tests, rehearsals) posting the feedback receive waits on the
+    host until the last stage's thread has enqueued the matching send — at most `hop_timeout_s` x stages."""
 
     remote = False
 

@@ -10,6 +10,7 @@ Errors use the `{"error": {"message", "type", "code"}}` envelope with a 4xx / 5x
 """
 from __future__ import annotations
 
+import asyncio
 import contextlib
 import json
 import time
@@ -164,28 +165,47 @@ def add_routes(routes: List, state: Dict, cors: Dict):
         def finish_reason():
             return "stop" if req.error == "cancelled" or not req.finished else _finish_reason(req, b.cfg)
 
+        def failure_response():
+            """A failed request as an HTTP answer: back-pressure is 429, a request the engine can
+            never serve is 400, anything else 500 — the same on every non-streamed path."""
+            err = req.error or ""
+            if err.startswith("queue full"):
+                return js(_error(err, 429, "rate_limit_error"), 429)
+            return js(failed(), 400 if "exceeds max_seq_len" in err or "empty prompt" in err else 500)
+
+        async def client_gone():
+            while (await request.receive()).get("type") != "http.disconnect":
+                pass
+
         if not stream and stops:                # the text has to be watched while it grows
+            async def collect():
+                return "".join([t async for t in filtered()])
+            # raced against the client's disconnect: a cancelled collector closes `pieces`, which
+            # cancels the request in the engine instead of decoding on for nobody
+            job, gone = asyncio.ensure_future(collect()), asyncio.ensure_future(client_gone())
             try:
-                text = "".join([t async for t in filtered()])
+                await asyncio.wait({job, gone}, return_when=asyncio.FIRST_COMPLETED)
+                if not job.done():
+                    job.cancel()
+                    with contextlib.suppress(asyncio.CancelledError, Exception):
+                        await job
+                    return js(_error("client disconnected", 408, "timeout"), 408)
+                text = job.result()
             except TimeoutError as e:
                 return js(_error(str(e), 408, "timeout"), 408)
+            finally:
+                gone.cancel()
             if req.state == "failed" and req.error != "cancelled":
-                return js(failed(), 500)
+                return failure_response()
             return js({"id": rid, "object": kind, "created": created, "model": b.model_name,
                        "choices": [choice(text, finish_reason())], "usage": _usage(req)})
 
         if not stream:
-            async def client_gone():
-                while (await request.receive()).get("type") != "http.disconnect":
-                    pass
             why = await b.wait_request(req, client_gone)
             if why is not None:
                 return js(_error(why, 408, "timeout"), 408)
             if req.state == "failed":
-                err = req.error or ""
-                if err.startswith("queue full"):
-                    return js(_error(err, 429, "rate_limit_error"), 429)
-                return js(failed(), 400 if "exceeds max_seq_len" in err or "empty prompt" in err else 500)
+                return failure_response()
             text = engine.tok.decode(req.output, skip_special_tokens=True)
             return js({"id": rid, "object": kind, "created": created, "model": b.model_name,
                        "choices": [choice(text, _finish_reason(req, b.cfg))], "usage": _usage(req)})

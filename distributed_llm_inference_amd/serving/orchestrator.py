@@ -50,6 +50,9 @@ class EngineBackend:
         self.restarts = 0
         self._factory = factory
         self._restart_lock = threading.Lock()
+        self._pipe_closed = False           # the current pipeline has been torn down for a rebuild that has not succeeded yet
+        self.restart_failures = 0
+        self._next_restart_at = 0.0
         self._streams = 0                   # open /generate streams (event-loop thread only)
 
     def _recover(self):
@@ -63,16 +66,36 @@ class EngineBackend:
         with self._restart_lock:
             if not self.engine.fatal:
                 return
+            # A bring-up that keeps failing (a GPU gone for good) must not be retried by every request:
+            # attempts are spaced 1, 2, 4 ... 60 s apart; in between, and when an attempt fails, the
+            # old engine stays in place with `fatal` set and answers with the error envelope.
+            now = time.monotonic()
+            if now < self._next_restart_at:
+                return
             import dataclasses
             from ..parallel.launcher import make_pipeline
-            try:
-                self.pipe.close()
-            except Exception:
-                pass
+            from ..utils.tracing import get_logger
+            if not self._pipe_closed:
+                try:
+                    self.pipe.close()
+                except Exception:
+                    pass
+                self._pipe_closed = True
             cfg = dataclasses.replace(self.cfg, fault_inject="")      # injected faults are one-shot
-            self.pipe = (self._factory or make_pipeline)(cfg)
+            try:
+                pipe = (self._factory or make_pipeline)(cfg)
+            except BaseException as e:              # noqa: BLE001 - the request that triggered the attempt is answered, not crashed
+                self.restart_failures += 1
+                self._next_restart_at = time.monotonic() + min(60.0, 2.0 ** min(self.restart_failures - 1, 6))
+                self.engine.fatal = f"{self.engine.fatal.split(' | restart failed')[0]} | restart failed: {type(e).__name__}: {e}"
+                get_logger().error("pipeline restart %d failed: %s: %s", self.restart_failures, type(e).__name__, e)
+                if not isinstance(e, Exception):
+                    raise
+                return
+            self.pipe, self._pipe_closed = pipe, False
             self.cfg, self.engine = self.pipe.cfg, self.pipe.engine
             self.restarts += 1
+            self.restart_failures, self._next_restart_at = 0, 0.0
 
     def generate(self, prompt, max_new_tokens, temperature, top_k=None, top_p=None, seed=None):
         self._recover()
@@ -169,8 +192,12 @@ class EngineBackend:
                 poked[0] = False
                 done = req.done.is_set()
                 n = len(req.output)
-                if n > sent_n:
-                    yield detok.push(req.output[:n], final=done), n
+                if n > sent_n or done:
+                    # the last pass always flushes: text held back behind an incomplete character must
+                    # leave even when no further token arrives (EOS is not appended to the output)
+                    text = detok.push(req.output[:n], final=done)
+                    if text:
+                        yield text, n
                     sent_n, t_sent = n, loop.time()
                 if done:
                     return
@@ -250,7 +277,9 @@ class EngineBackend:
         return render(self.engine.snapshot(), self.pipe.board, self.cfg.pp_size)
 
     def close(self):
-        self.pipe.close()
+        if not self._pipe_closed:
+            self._pipe_closed = True
+            self.pipe.close()
 
 
 class HttpRelayBackend:
@@ -304,6 +333,9 @@ class HttpRelayBackend:
             eos = getattr(self.tok, "eos_token_id", None)
             cached = 0
             debug = []
+            gen = None
+            if seed is not None:                      # a seeded request draws from its own generator, reproducibly
+                gen = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
             for step in range(n):
                 if self.incremental:
                     new = ids[cached:]
@@ -317,7 +349,7 @@ class HttpRelayBackend:
                 logits = self.edge.head_logits(hidden[0, -1:, :])[0]
                 if self.cfg.debug_top5 and step < 3:                                      # orchestration.py:172-178
                     debug.append(top_candidates(logits, temperature, top_k, top_p, 5))
-                nxt = sample_token(logits, temperature, top_k, top_p)
+                nxt = sample_token(logits, temperature, top_k, top_p, generator=gen)
                 if eos is not None and nxt == eos:
                     break
                 ids = ids + [nxt]
@@ -468,21 +500,25 @@ def create_app(backend):
 
 
 def _status_page(b) -> str:
-    rows = "".join(f"<p>{d}</p>" for d in (b.worker_descriptions() if b else ["not initialized"]))
+    """`GET /`: what is being served and by which stages (the reference shows its worker URLs:
+    orchestration.py:236-295). Own markup."""
+    stages = "".join(f"<li>{d}</li>" for d in (b.worker_descriptions() if b else ["not initialized"]))
     model = b.model_name if b else "-"
-    return f"""<!DOCTYPE html><html><head><title>Distributed LLM API</title>
-<style>body{{font-family:Arial,sans-serif;max-width:900px;margin:50px auto;padding:30px;
-background:linear-gradient(135deg,#667eea 0%,#764ba2 100%);color:white}}
-.container{{background:rgba(255,255,255,0.1);padding:40px;border-radius:20px}}
-.status{{display:inline-block;background:#4CAF50;padding:8px 20px;border-radius:25px;font-weight:bold}}
-.section{{background:rgba(0,0,0,0.2);padding:20px;border-radius:10px;margin:20px 0}}</style></head>
-<body><div class="container"><h1>Distributed LLM API</h1>
-<h2>Status: <span class="status">{'ONLINE' if b else 'STARTING'}</span></h2>
-<div class="section"><h3>Model</h3><p>{model}</p><p>Engine {VERSION}: layer-split pipeline on MI355X,
-paged KV cache, temperature / top-k / top-p sampling, chat formatting.</p></div>
-<div class="section"><h3>Workers</h3>{rows}</div>
-<div class="section"><h3>Routes</h3><p>GET /health &middot; GET /workers &middot; POST /generate &middot; GET /metrics</p></div>
-</div></body></html>"""
+    state = "serving" if b else "starting"
+    return f"""<!DOCTYPE html><html><head><meta charset="utf-8"><title>layer-split LLM inference</title>
+<style>body{{font:15px/1.55 system-ui,sans-serif;margin:3rem auto;max-width:46rem;color:#17212b;background:#f6f7f9}}
+header{{display:flex;justify-content:space-between;align-items:baseline;border-bottom:2px solid #17212b;margin-bottom:1.2rem}}
+.state{{font:600 .8rem ui-monospace,monospace;text-transform:uppercase;letter-spacing:.08em;color:#0a7d38}}
+dl{{display:grid;grid-template-columns:9rem 1fr;gap:.3rem 1rem}}dt{{font-weight:600}}dd{{margin:0}}
+code{{font:.85rem ui-monospace,monospace;background:#e6e9ee;padding:.1rem .3rem;border-radius:3px}}
+ul{{margin:.2rem 0;padding-left:1.1rem}}</style></head>
+<body><header><h1>Layer-split LLM inference</h1><span class="state">{state}</span></header>
+<dl><dt>model</dt><dd>{model}</dd>
+<dt>engine</dt><dd>{VERSION}: pipeline stages on MI355X, paged KV cache, continuous batching,
+temperature / top-k / top-p sampling, chat formatting</dd>
+<dt>stages</dt><dd><ul>{stages}</ul></dd>
+<dt>routes</dt><dd><code>GET /health</code> <code>GET /workers</code> <code>POST /generate</code>
+<code>GET /metrics</code> <code>GET /ready</code> <code>/v1/*</code></dd></dl></body></html>"""
 
 
 def create_asgi_app(backend):

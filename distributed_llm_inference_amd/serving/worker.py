@@ -93,12 +93,15 @@ def create_worker_app(service: Optional[WorkerService]):
         if s is None:
             return "<html><body><h1>worker not initialized</h1></body></html>"
         p = s.plan
-        return (f"<html><head><title>{s.worker_name}</title></head>"
-                f"<body style=\"font-family:Arial;padding:40px;background:#e3f2fd;\">"
-                f"<h1>{s.worker_name} (Layers {p.layer_start}-{p.layer_end})</h1>"
-                f"<h2>Status: <span style=\"color:green;\">ONLINE</span></h2>"
-                f"<p>Model: {s.model_name}</p><p>Loaded {p.num_layers} layers</p>"
-                f"<p>Backend: {s.ex.backend}; requests served: {s.requests}</p></body></html>")
+        # a status page like the reference's worker has (Worker1.py:185-197), own markup: a table of facts
+        facts = [("stage", s.worker_name), ("decoder layers", f"{p.layer_start} to {p.layer_end} ({p.num_layers})"),
+                 ("model", s.model_name), ("executor", s.ex.backend), ("hidden-state requests served", s.requests)]
+        rows = "".join(f"<tr><th>{k}</th><td>{v}</td></tr>" for k, v in facts)
+        return ("<!DOCTYPE html><html><head><meta charset=\"utf-8\"><title>pipeline stage</title>"
+                "<style>body{font:15px/1.5 system-ui,sans-serif;margin:3rem auto;max-width:36rem;color:#1c2733}"
+                "table{border-collapse:collapse;width:100%}th,td{text-align:left;padding:.35rem .6rem;border-bottom:1px solid #d5dbe1}"
+                "th{width:45%;font-weight:600}.up{color:#0a7d38}</style></head>"
+                f"<body><h1>Pipeline stage <span class=\"up\">up</span></h1><table>{rows}</table></body></html>")
 
     @app.route("/health", methods=["GET"])
     def health():

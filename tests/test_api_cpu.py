@@ -43,7 +43,7 @@ def test_orchestrator_routes(backend):
     r = c.get("/workers")
     assert r.get_json() == {"worker_1": "online", "worker_2": "online"}
     r = c.get("/")
-    assert r.status_code == 200 and b"Distributed LLM API" in r.data and b"stage 1" in r.data
+    assert r.status_code == 200 and b"Layer-split LLM inference" in r.data and b"stage 1" in r.data
     r = c.post("/generate", json={"prompt": "Hello", "max_tokens": 6})
     d = r.get_json()
     assert r.status_code == 200 and d["status"] == "success" and d["prompt"] == "Hello"
@@ -76,7 +76,7 @@ def test_asgi_app_serves_the_same_contract(backend):
         assert r.status_code == 200 and set(r.json()) == {"status", "role", "model", "version"}
         assert c.get("/workers").json() == {"worker_1": "online", "worker_2": "online"}
         r = c.get("/")
-        assert r.status_code == 200 and "Distributed LLM API" in r.text and "stage 1" in r.text
+        assert r.status_code == 200 and "Layer-split LLM inference" in r.text and "stage 1" in r.text
         r = c.post("/generate", json={"prompt": "Hello", "max_tokens": 6})
         d = r.json()
         assert r.status_code == 200 and d["status"] == "success" and d["prompt"] == "Hello"
@@ -215,6 +215,41 @@ def test_streaming_generate_sends_the_text_as_it_is_decoded(backend):
     first = asyncio.run(first_piece_only())
     assert first.startswith("data: {") and "text" in json.loads(first[6:])
     assert eng.wait_idle(30) and eng.alloc.used == 0 and eng.stats["cancelled"] == before + 1
+
+
+def test_streamed_text_equals_the_decoded_output_when_the_request_ends_inside_a_character(backend):
+    """A request that ends (EOS is not appended, or the cap is hit) while the detokenizer still
+    holds back the bytes of an unfinished character: the stream must flush them on its last pass,
+    so that streamed and non-streamed text agree, and must never send an empty piece."""
+    import asyncio
+    from distributed_llm_inference_amd.runtime.engine import Request
+    tok = backend.engine.tok
+    ids = tok.encode("ok é", add_special_tokens=False)[:-1]          # ends on the first byte of a two-byte character
+
+    async def run():
+        req = Request(rid=10 ** 6, prompt_ids=[1], params=SamplingParams(), eos_id=None)
+        req.state = "running"
+        got = []
+
+        async def feed():
+            for i in range(len(ids)):
+                req.output.append(ids[i])
+                for cb in req.token_callbacks:
+                    cb(req)
+                await asyncio.sleep(0.01)
+            req.state = "finished"                   # EOS arrives: no further token, only the done flag
+            req._set_done()
+
+        feeder = asyncio.ensure_future(feed())
+        async for text, n in backend.pieces(req):
+            got.append((text, n))
+        await feeder
+        return got
+
+    got = asyncio.run(run())
+    assert all(t for t, _ in got)
+    assert "".join(t for t, _ in got) == tok.decode(ids, skip_special_tokens=True)
+    assert got[-1][1] == len(ids)
 
 
 def test_client_library_streams(backend):
@@ -552,6 +587,45 @@ def test_auto_restart_rebuilds_the_pipeline_after_a_stage_died():
         assert second["status"] == "success" and second["tokens_generated"] == 6, second
         assert b.restarts == 1
         assert b.workers() == {"worker_1": "online", "worker_2": "online"}
+    finally:
+        b.close()
+
+
+def test_a_failed_bring_up_leaves_no_shared_memory_behind():
+    """A stage that raises while coming up (here: the HIP executor asked for on a machine without a
+    GPU): the constructor raises, and since the caller gets no object to close, the attempt's rings
+    and status board must be gone from /dev/shm already."""
+    import glob
+    if torch.cuda.device_count() > 0:
+        pytest.skip("needs a machine without a GPU to make the stage fail at bring-up")
+    before = set(glob.glob(f"/dev/shm/dlia_{os.getpid()}_*"))
+    with pytest.raises(RuntimeError, match="bring-up failed"):
+        make_pipeline(cfg(pp_size=2, partition="even", transport="gloo", backend="hip", device="cpu"))
+    assert set(glob.glob(f"/dev/shm/dlia_{os.getpid()}_*")) == before
+
+
+def test_a_restart_that_fails_answers_with_the_envelope_and_is_not_retried_by_every_request():
+    """auto_restart with a pipeline that cannot be rebuilt: requests get the reference's error
+    envelope (never an exception out of the route), and the rebuild is attempted once per back-off
+    interval, not once per request."""
+    calls = []
+
+    def factory(c):
+        calls.append(time.monotonic())
+        raise RuntimeError("no GPU left")
+
+    b = EngineBackend(LocalPipeline(cfg(auto_restart=True)), factory=factory)
+    try:
+        b.engine._fatal("stage 0 failed: injected")
+        outs = [b.generate("Hello", 4, 0.0) for _ in range(5)]
+        assert all(o["status"] == "failed" and "restart failed" in o["error"] for o in outs), outs
+        assert len(calls) == 1 and b.restart_failures == 1 and b.restarts == 0
+        # the asynchronous routes answer the same way
+        import asyncio
+        out = asyncio.run(b.agenerate("Hello", 4, 0.0))
+        assert out["status"] == "failed" and len(calls) == 1
+        b._next_restart_at = 0.0                       # the back-off has passed
+        assert b.generate("Hello", 4, 0.0)["status"] == "failed" and len(calls) == 2
     finally:
         b.close()
 

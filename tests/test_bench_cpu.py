@@ -55,6 +55,55 @@ def test_single_rank_prints_one_json_line():
     assert r["config"]["micro_batches"] == 2           # 2 x gpus
 
 
+def test_gpus_n_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the command starts two rank
+    processes itself and prints the one line with n_gpus = 2 — stdout carries that line and nothing
+    else — with what a reader needs to check a scaling run: every rank, its transport, the hops timed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "2"
+    p = subprocess.run([sys.executable, BENCH, "--cpu", "--gpus", "2", "--model", "tiny-llama-test", "--steps", "3",
+                        "--warmup", "1", "--max-seconds", "240"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    assert len(p.stdout.strip().splitlines()) == 1, p.stdout
+    r = _check(p.stdout.strip(), 2, 3, 1)
+    assert r["config"]["launcher"] == "self" and r["config"]["transport"] == "gloo"
+    assert [x["rank"] for x in r["ranks"]] == [0, 1] and all(x["transport"] == "gloo" and x["ms_per_step"] > 0 for x in r["ranks"])
+    assert {h["hop"] for h in r["hops"]} == {"0->1", "1->0 (tokens)"} and all(h["us_min"] > 0 for h in r["hops"])
+    # the low-latency regions ride in the same line, timed the same way
+    for key, rows in (("latency_point", 8), ("single_request", 1)):
+        pt = r[key]
+        assert pt["batch"] == rows and pt["micro_batches"] == 1 and pt["ms_per_token"] > 0
+        assert abs(pt["tok_s"] - rows / (pt["ms_per_token"] * 1e-3)) <= 0.01 * pt["tok_s"]
+
+
+def test_a_launcher_with_another_world_size_is_an_error_not_a_smaller_run():
+    """--gpus 4 under a launcher that started 2 ranks (or 1) must fail, never quietly run PP=2."""
+    for ws in ("2", "1"):
+        env = dict(os.environ, WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        p = subprocess.run([sys.executable, BENCH, "--cpu", "--gpus", "4", "--model", "tiny-llama-test"],
+                           capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+        assert p.returncode == 2 and "WORLD_SIZE" in p.stderr and not _json_lines(p.stdout), (p.returncode, p.stderr[-500:])
+
+
+def test_a_failing_rank_fails_the_self_launched_job():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, BENCH, "--cpu", "--gpus", "2", "--model", "no-such-model", "--max-seconds", "60"],
+                       capture_output=True, text=True, timeout=200, cwd=ROOT, env=env)
+    assert p.returncode != 0 and not _json_lines(p.stdout)
+
+
+def test_preflight_opens_times_and_closes_every_hop():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, BENCH, "--cpu", "--gpus", "3", "--preflight"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip())
+    assert r["n_gpus"] == 3 and r["transport"] == "gloo" and r["seconds"] < 20
+    assert {h["hop"] for h in r["hops"]} == {"0->1", "1->2", "2->0 (tokens)"}
+    assert "hop 1->2" in p.stderr
+
+
 def test_two_ranks_under_torch_distributed_run():
     """The driver's N > 1 launch line: one rank per stage, rank 0 prints the line, the others none."""
     env = dict(os.environ, OMP_NUM_THREADS="2")

@@ -525,3 +525,32 @@ def test_stage_processes_end_when_their_serving_process_is_killed(tmp_path):
     assert not left, left
     import glob
     assert not glob.glob("/dev/shm/dlia_%d_*" % p.pid)         # ... and took the job's shared memory with them
+
+
+def test_a_request_cancelled_right_after_submit_never_runs():
+    """submit() and cancel() both before the scheduler's next tick: the request is answered as
+    cancelled once, takes no row and no KV blocks, and is counted once."""
+    from distributed_llm_inference_amd.parallel.launcher import LocalPipeline
+    pipe = LocalPipeline(EngineConfig(model="tiny-llama-test", pp_size=1, max_batch=2, num_micro_batches=1, max_seq_len=96,
+                                      prefill_chunk=32, backend="torch", device="cpu", transport="loopback", seed=1))
+    eng = pipe.engine
+    try:
+        eng._stop = True                            # scheduler paused: both calls land before one tick
+        eng._wake.set()
+        eng._thread.join(10)
+        eng._thread, eng._stop = None, False
+        fired = []
+        req = eng.submit(list(range(5, 25)), SamplingParams(temperature=0.0, max_new_tokens=16, stop_on_eos=False))
+        req.add_done_callback(lambda r: fired.append(r.state))
+        eng.cancel(req)
+        eng._cancel(eng._cancel_box.popleft())      # the order the race produces: cancelled while still in the inbox
+        eng.start()
+        other = eng.submit(list(range(5, 15)), SamplingParams(temperature=0.0, max_new_tokens=4, stop_on_eos=False)).wait(60)
+        assert other.state == "finished" and len(other.output) == 4
+        assert eng.wait_idle(10)
+        assert req.state == "failed" and req.error == "cancelled" and req.output == [] and req.row == -1
+        assert fired == ["failed"]
+        st = eng.snapshot()
+        assert st["cancelled"] == 1 and st["completed"] == 1 and st["kv_blocks_used"] == 0
+    finally:
+        pipe.close()

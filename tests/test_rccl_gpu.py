@@ -47,6 +47,29 @@ def test_self_hop_round_trips_hidden_states_and_token_ids(edge):
     assert st["ops"] >= 2 and st["bytes_sent"] >= src.numel() * 2 + ids.numel() * 4
 
 
+def test_completion_ring_wraps_without_aliasing_tokens(edge):
+    """More transfers than the edge has completion events (256): every transfer still delivers its own
+    bytes, a token whose slot has been reused since reads as complete (its transfer finished before the
+    slot was handed on) instead of waiting for the newer transfer, and tokens never repeat."""
+    src = torch.zeros(64, device="cuda", dtype=torch.int32)
+    dst = torch.zeros(700, 64, device="cuda", dtype=torch.int32)
+    first = None
+    toks = set()
+    for i in range(700):
+        src.fill_(i)
+        h = edge.sendrecv(src, dst[i])
+        h.wait()                                 # the next fill_ must not overtake the send
+        first = first or h
+        toks.add(h.token)
+    assert len(toks) == 700
+    assert first.done()                          # expired token: complete by construction
+    first.wait()
+    first.sync(1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, 0].cpu(), torch.arange(700, dtype=torch.int32))
+    assert torch.equal(dst.min(dim=1).values, dst.max(dim=1).values)
+
+
 def test_hop_is_ordered_behind_its_producer_and_ahead_of_its_consumer(edge):
     """The transfer must see what the compute stream wrote just before `send`, and work enqueued
     after `wait()` must see the received bytes — with a long-running producer in front."""
