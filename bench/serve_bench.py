@@ -117,12 +117,18 @@ def main():
     out_tokens = sum(len(r.output) for r in reqs)
     ttft = sorted((r.t_first - r.t_arrival) * 1e3 for r in reqs if r.t_first)
     tpot = sorted(((r.t_done - r.t_first) / max(1, len(r.output) - 1)) * 1e3 for r in reqs if r.t_first and r.t_done)
+    # inter-token latency: every gap between two consecutive tokens of a request after its first (the
+    # gap behind the first token is reported separately: a request whose prompt is done early waits there
+    # until the rest of its micro-batch has been prefilled)
+    itl = sorted((b - a) * 1e3 for r in reqs for a, b in zip(r.token_times[1:], r.token_times[2:]))
+    second = sorted((r.token_times[1] - r.token_times[0]) * 1e3 for r in reqs if len(r.token_times) > 1)
     q = lambda v, p: v[min(len(v) - 1, int(p * len(v)))] if v else None
     print(json.dumps({"model": eng.spec.name, "requests": a.requests, "seconds": round(dt, 3),
                       "prompt_tokens": sum(len(p) for p in prompts), "output_tokens": out_tokens,
                       "output_tok_per_s": round(out_tokens / dt, 1), "requests_per_s": round(a.requests / dt, 2),
                       "ttft_ms_p50": q(ttft, 0.5), "ttft_ms_p99": q(ttft, 0.99), "tpot_ms_p50": q(tpot, 0.5),
-                      "tpot_ms_p99": q(tpot, 0.99), "recompositions": snap.get("recompositions"),
+                      "tpot_ms_p99": q(tpot, 0.99), "itl_ms_p50": q(itl, 0.5), "itl_ms_p99": q(itl, 0.99),
+                      "first_to_second_token_ms_p50": q(second, 0.5), "recompositions": snap.get("recompositions"),
                       "config": {"max_batch": a.batch, "micro_batches": a.micro_batches, "pp": a.pp_size, "dtype": a.dtype, "kv_dtype": a.kv_dtype,
                                  "isolate": a.isolate, "closed_loop_clients": a.closed_loop, "stagger_ms": a.stagger_ms},
                       "steps": {k: snap.get(k) for k in ("prefill_steps", "decode_steps", "preemptions")}}))

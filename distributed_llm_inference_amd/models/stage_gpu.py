@@ -22,6 +22,7 @@ import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 
 from .. import ops
@@ -34,6 +35,33 @@ from .weights import StageWeights
 
 BLOCK = packing.KV_BLOCK
 DEFAULT_DECODE_ROWS = 256      # row count up to which GEMMs take the weight-streaming kernel (with split-K partials)
+
+
+class _PinnedRing:
+    """Pinned host staging for step metadata. Everything a step tells the device — token positions,
+    sequence slots, sampling parameters, block-table rows — is packed into ONE of these buffers and
+    leaves in one asynchronous copy, so building a step never waits for the device (a pageable
+    `tensor.to(device)` does: it is ordered behind the stream's queued work and blocks the host until
+    it has run). A buffer is reused only after the copy that read it has executed."""
+
+    def __init__(self, words: int, slots: int = 8):
+        self.words = words
+        self.bufs = [torch.empty(words, dtype=torch.int32).pin_memory() for _ in range(slots)]
+        self.views = [b.numpy() for b in self.bufs]
+        self.events: List[Optional[torch.cuda.Event]] = [None] * slots
+        self.i = 0
+
+    def take(self):
+        k = self.i
+        self.i = (k + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        return k, self.views[k], self.bufs[k]
+
+    def sent(self, k: int):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
 
 
 @dataclass
@@ -58,6 +86,7 @@ class _Work:
 class _MicroBatchState:
     """Static device buffers (and the captured graph) of one in-flight decode micro-batch."""
     B: int
+    params: torch.Tensor         # int32 [9 B] the per-row fields below, contiguous: a new composition is ONE upload
     slots: torch.Tensor          # int32 [B]   KV slot of each row (= tok_seq for decode)
     ctx: torch.Tensor            # int32 [B]   cached tokens (= tok_pos for decode); advanced in-graph
     ids: torch.Tensor            # int32 [B]   stage-0 input tokens
@@ -171,12 +200,12 @@ class GpuStage:
         self._ws_floats = need
         self._gemm_shapes = [(spec.qkv_size, H), (H, spec.q_size), (H, I), (2 * I if spec.is_llama else I, H)]
         self.wk0 = self._new_work(self.max_tokens)
-        # eager-path metadata (device) + pinned staging
-        i32 = lambda n: torch.zeros(n, device=dev, dtype=torch.int32)
-        MT = self.max_tokens
-        self.md_tok_pos, self.md_tok_seq = i32(MT), i32(MT)
-        self.md_q_start, self.md_ctx, self.md_slots = i32(max_batch + 1), i32(max_batch), i32(max_batch)
-        self.md_rows, self.md_ids = i32(max_batch), i32(MT)
+        # step metadata: pinned staging ring (host) and one landing buffer per stream (device)
+        self._table_cap = 1 << 16                   # words of one block-table upload; larger updates go in pieces
+        self._md_words = 3 * self.max_tokens + 16 * max_batch + 64
+        self._ring = _PinnedRing(max(self._md_words, self._table_cap))
+        self._landing: Dict[int, torch.Tensor] = {}
+        self._eager_sampling = None                 # (step id, device views) staged by `forward` for `sample`
         # ---- paged KV cache for this stage's layers ---------------------------------------
         # (after the workspaces: the cache takes what is left of the device)
         self.kv_mem_fraction, self.decode_states = kv_mem_fraction, max(1, decode_states)
@@ -302,16 +331,65 @@ class GpuStage:
         self.kv_scale = (torch.zeros(max(L, 1), self.num_blocks, s.num_kv_heads, 2, BLOCK, device=dev)
                          if self.kv8 else None)
 
+    # ---- step metadata: host -> device ------------------------------------------------------
+    def _land(self) -> torch.Tensor:
+        """The current stream's landing buffer: uploads and the kernels that read them are ordered
+        by the stream, so one buffer per stream is enough (eager steps run on the main stream,
+        every decode micro-batch on its own)."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        buf = self._landing.get(key)
+        if buf is None:
+            buf = torch.zeros(self._ring.words, device=self.device, dtype=torch.int32)
+            self._landing[key] = buf
+        return buf
+
+    def _upload(self, parts, dst: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+        """Packs 1-D numpy arrays (int32 / float32 / int64) into one pinned buffer and copies it to
+        `dst` (default: the stream's landing buffer) asynchronously. Returns typed device views."""
+        dst = self._land() if dst is None else dst
+        k, hv, hb = self._ring.take()
+        off, spans = 0, []
+        for a in parts:
+            a = np.ascontiguousarray(a)
+            if a.dtype == np.int64:
+                off += off & 1                      # 8-byte alignment of int64 views
+            w = a.size * (a.dtype.itemsize // 4)
+            if off + w > self._ring.words or off + w > dst.numel():
+                raise ValueError(f"step metadata of {off + w} words exceeds the staging buffer ({min(self._ring.words, dst.numel())})")
+            hv[off:off + w] = a.view(np.int32)
+            spans.append((off, w, a.dtype))
+            off += w
+        if off:
+            dst[:off].copy_(hb[:off], non_blocking=True)
+        self._ring.sent(k)
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int64): torch.int64}
+        return [dst[o:o + w] if dt not in tdt else dst[o:o + w].view(tdt[dt]) for o, w, dt in spans]
+
     # ---- block tables ---------------------------------------------------------------------
-    def set_tables(self, batch: StepBatch):
-        for slot, blocks in zip(batch.table_slots, batch.table_blocks):
+    def _write_table_rows(self, slots: List[int], tables: List[List[int]]):
+        """block_table[slot] = blocks (padded with -1) for each pair: rows travel through the staging
+        ring and a scatter kernel, `_table_cap` words at a time."""
+        n, mb = len(slots), self.max_blocks
+        if n == 0:
+            return
+        vals = np.full((n, mb), -1, dtype=np.int32)
+        for i, (slot, blocks) in enumerate(zip(slots, tables)):
             if not (0 <= slot < self.max_slots):
                 raise ValueError(f"slot {slot} out of range")
-            if len(blocks) > self.max_blocks or any(b < 0 or b >= self.num_blocks for b in blocks):
+            if len(blocks) > mb:
                 raise ValueError(f"bad block table for slot {slot}")
-            row = torch.full((self.max_blocks,), -1, dtype=torch.int32)
-            row[:len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
-            self.block_table[slot].copy_(row.to(self.device, non_blocking=False))
+            if blocks:
+                vals[i, :len(blocks)] = blocks
+                if min(blocks) < 0 or max(blocks) >= self.num_blocks:
+                    raise ValueError(f"bad block table for slot {slot}")
+        rows = np.asarray(slots, dtype=np.int32)
+        per = max(1, self._table_cap // (mb + 1))
+        for i in range(0, n, per):
+            r, v = self._upload([rows[i:i + per], vals[i:i + per].reshape(-1)])
+            self.K.scatter_rows(self.block_table, r, v.view(-1, mb))
+
+    def set_tables(self, batch: StepBatch):
+        self._write_table_rows(batch.table_slots, batch.table_blocks)
 
     def apply_growth(self, batch: StepBatch):
         """block_table[slot][pos] = block for the sequences that got one more block this step.
@@ -319,17 +397,15 @@ class GpuStage:
         n = len(batch.grow_slots)
         if n == 0:
             return
-        for slot, pos, blk in zip(batch.grow_slots, batch.grow_pos, batch.grow_blocks):
-            if not (0 <= slot < self.max_slots and 0 <= pos < self.max_blocks and 0 <= blk < self.num_blocks):
-                raise ValueError(f"bad block-table growth: slot {slot} pos {pos} block {blk}")
-        idx = torch.tensor([s_ * self.max_blocks + p_ for s_, p_ in zip(batch.grow_slots, batch.grow_pos)], dtype=torch.int64)
-        val = torch.tensor(batch.grow_blocks, dtype=torch.int32)
-        self.block_table.view(-1).index_copy_(0, idx.to(self.device), val.to(self.device))
+        sl, ps, bl = (np.asarray(v, dtype=np.int64) for v in (batch.grow_slots, batch.grow_pos, batch.grow_blocks))
+        if ((sl < 0) | (sl >= self.max_slots) | (ps < 0) | (ps >= self.max_blocks) | (bl < 0) | (bl >= self.num_blocks)).any():
+            raise ValueError("bad block-table growth entry")
+        idx, val = self._upload([(sl * self.max_blocks + ps).astype(np.int32), bl.astype(np.int32)])
+        self.K.scatter(self.block_table, idx, val)
 
     def release(self, slots: List[int]):
-        for s in slots:
-            if 0 <= s < self.max_slots:
-                self.block_table[s].fill_(-1)
+        ok = [s for s in slots if 0 <= s < self.max_slots]
+        self._write_table_rows(ok, [[]] * len(ok))
 
     # ---- the layer stack on T tokens ------------------------------------------------------
     def _cfg(self, M: int, N: int, K: int, epi: int):
@@ -448,57 +524,78 @@ class GpuStage:
         self.set_tables(batch)
         self.apply_growth(batch)
         wk = self.wk0
-        tok_pos, tok_seq, q_start, rows = [], [], [0], []
-        for slot, q, c, smp in zip(batch.slots, batch.q_lens, batch.ctx_lens, batch.sample):
-            if c + q > self.max_seq_len:
-                raise ValueError(f"sequence in slot {slot} would reach {c + q} tokens > max_seq_len {self.max_seq_len}")
-            tok_pos += list(range(c, c + q))
-            tok_seq += [slot] * q
-            q_start.append(q_start[-1] + q)
-            if smp and q > 0:
-                rows.append(q_start[-1] - 1)
+        q = np.asarray(batch.q_lens, dtype=np.int64)
+        c = np.asarray(batch.ctx_lens, dtype=np.int64)
+        slots = np.asarray(batch.slots, dtype=np.int32)
+        if B and int((c + q).max()) > self.max_seq_len:
+            i = int(np.argmax(c + q))
+            raise ValueError(f"sequence in slot {batch.slots[i]} would reach {int(c[i] + q[i])} tokens > max_seq_len {self.max_seq_len}")
+        q_start = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(q, out=q_start[1:])
+        tok_seq = np.repeat(slots, q)
+        tok_pos = (np.arange(T, dtype=np.int64) - np.repeat(q_start[:-1] - c, q)).astype(np.int32)
+        sampled = (np.asarray(batch.sample, dtype=np.int64) != 0) & (q > 0)
+        rows = (q_start[1:][sampled] - 1).astype(np.int32)
+        R = int(rows.size)
+        if R > self.max_batch:
+            raise ValueError(f"{R} sampled rows exceed max_batch {self.max_batch}")
         dev = self.device
-        up = lambda dst, vals: dst[:len(vals)].copy_(torch.tensor(vals, dtype=torch.int32), non_blocking=False)
-        up(self.md_tok_pos, tok_pos); up(self.md_tok_seq, tok_seq); up(self.md_q_start, q_start)
-        up(self.md_ctx, batch.ctx_lens); up(self.md_slots, batch.slots)
+        parts = [tok_pos, tok_seq, q_start.astype(np.int32), c.astype(np.int32), slots, rows]
+        host_ids = self.plan.has_embed and not (torch.is_tensor(x) and x.is_cuda)
+        if host_ids:
+            ids_h = x.numpy() if torch.is_tensor(x) else np.asarray(x)
+            ids_h = ids_h.astype(np.int32, copy=False).reshape(-1)
+            if ids_h.size != T:
+                raise ValueError(f"expected {T} token ids, got {ids_h.size}")
+            parts.append(ids_h)
+        if self.plan.has_head and R:
+            pick = lambda vals, dt: np.asarray(vals, dtype=dt)[sampled]
+            parts += [pick(batch.temperature, np.float32), pick(batch.top_k, np.int32), pick(batch.top_p, np.float32),
+                      pick(batch.sample_steps, np.int32), pick(batch.seeds, np.int64)]
+        up = self._upload(parts)
+        md_tok_pos, md_tok_seq, md_q_start, md_ctx, md_slots, md_rows = up[:6]
+        nxt = 6
         if self.plan.has_embed:
-            ids = x.to(device=dev, dtype=torch.int32).reshape(-1)
-            if ids.numel() != T:
-                raise ValueError(f"expected {T} token ids, got {ids.numel()}")
-            self.K.embed(wk.h[:T], ids, self.md_tok_pos[:T], self.embed, self.pos_embed)
+            if host_ids:
+                ids = up[nxt]
+                nxt += 1
+            else:
+                ids = x.to(dtype=torch.int32).reshape(-1)
+                if ids.numel() != T:
+                    raise ValueError(f"expected {T} token ids, got {ids.numel()}")
+            self.K.embed(wk.h[:T], ids, md_tok_pos, self.embed, self.pos_embed)
         else:
             if tuple(x.shape) != (T, s.hidden_size):
                 raise ValueError(f"expected hidden [{T},{s.hidden_size}], got {tuple(x.shape)}")
-            wk.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16))
-        max_q = max(batch.q_lens) if batch.q_lens else 1
-        pend = self._layers(wk, T, B, self.md_tok_pos[:T], self.md_tok_seq[:T], self.md_q_start[:B + 1], self.md_ctx[:B],
-                            self.md_slots[:B], max_q, 1, alone=True)
+            wk.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16), non_blocking=True)
+        self._eager_sampling = (batch.step_id, R, up[nxt:nxt + 5]) if (self.plan.has_head and R) else None
+        max_q = int(q.max()) if B else 1
+        pend = self._layers(wk, T, B, md_tok_pos, md_tok_seq, md_q_start, md_ctx, md_slots, max_q, 1, alone=True)
         if not self.plan.has_head:
             self._fold(wk, T, pend)
             return wk.h[:T]
-        R = len(rows)
         if R == 0:
             return wk.logits[:0, :s.vocab_size]
-        if R > self.max_batch:
-            raise ValueError(f"{R} sampled rows exceed max_batch {self.max_batch}")
-        up(self.md_rows, rows)
-        return self._head(wk, self.md_rows, R, T, pend)[:, :s.vocab_size]
+        return self._head(wk, md_rows, R, T, pend)[:, :s.vocab_size]
 
     @torch.no_grad()
     def sample(self, batch: StepBatch, logits: torch.Tensor) -> torch.Tensor:
         """Tokens (device int32 [num_samples]) for the rows `forward` returned logits for."""
         idx = [i for i in range(batch.num_seqs) if batch.sample[i] and batch.q_lens[i] > 0]
         R = len(idx)
-        dev = self.device
-        out = torch.empty(R, device=dev, dtype=torch.int32)
+        out = torch.empty(R, device=self.device, dtype=torch.int32)
         if R == 0:
             return out
-        t = lambda vals, dt: torch.tensor(vals, dtype=dt).to(dev)
+        staged = self._eager_sampling
+        if staged is not None and staged[0] == batch.step_id and staged[1] == R:
+            temp, top_k, top_p, steps, seeds = staged[2]          # uploaded with the step's other metadata
+        else:
+            pick = lambda vals, dt: np.asarray([vals[i] for i in idx], dtype=dt)
+            temp, top_k, top_p, steps, seeds = self._upload([pick(batch.temperature, np.float32), pick(batch.top_k, np.int32),
+                                                              pick(batch.top_p, np.float32), pick(batch.sample_steps, np.int32),
+                                                              pick(batch.seeds, np.int64)])
         lg = self.wk0.logits[:R]  # `logits` is a view of this buffer (padded columns ignored by `vocab`)
-        self.K.sample(out, lg, t([batch.temperature[i] for i in idx], torch.float32),
-                      t([batch.top_k[i] for i in idx], torch.int32), t([batch.top_p[i] for i in idx], torch.float32),
-                      t([batch.seeds[i] for i in idx], torch.int64), t([batch.sample_steps[i] for i in idx], torch.int32),
-                      self.spec.vocab_size, None, None)
+        self.K.sample(out, lg, temp, top_k, top_p, seeds, steps, self.spec.vocab_size, None, None)
         return out
 
     # ---- graph-captured decode ------------------------------------------------------------
@@ -510,14 +607,18 @@ class GpuStage:
             for k in [k for k in self._mbs if k[0] == mb and k[1] not in self.graph_sizes]:
                 del self._mbs[k]
         dev, H = self.device, self.spec.hidden_size
-        i32 = lambda: torch.zeros(B, device=dev, dtype=torch.int32)
+        # per-row fields in one buffer, in upload order: slots | ctx | top_k | steps | temperature | top_p | seeds (int64) | ids
+        params = torch.zeros(9 * B + 2, device=dev, dtype=torch.int32)
+        field = lambda i, n=1: params[i * B:(i + n) * B]
+        params[:B] = self.null_slot
+        field(5).view(torch.float32).fill_(1.0)
         st = _MicroBatchState(
-            B=B, slots=torch.full((B,), self.null_slot, device=dev, dtype=torch.int32), ctx=i32(), ids=i32(),
+            B=B, params=params, slots=field(0), ctx=field(1), ids=field(8),
             hidden_in=None if self.plan.has_embed else torch.zeros(B, H, device=dev, dtype=torch.bfloat16),
             hidden_out=None if self.plan.has_head else torch.zeros(B, H, device=dev, dtype=torch.bfloat16),
-            tokens=i32() if self.plan.has_head else None,
-            temperature=torch.zeros(B, device=dev), top_k=i32(), top_p=torch.ones(B, device=dev),
-            seeds=torch.zeros(B, device=dev, dtype=torch.int64), steps=i32(), wk=self._new_work(B))
+            tokens=torch.zeros(B, device=dev, dtype=torch.int32) if self.plan.has_head else None,
+            temperature=field(4).view(torch.float32), top_k=field(2), top_p=field(5).view(torch.float32),
+            seeds=field(6, 2).view(torch.int64), steps=field(3), wk=self._new_work(B))
         self._mbs[(mb, B)] = st
         return st
 
@@ -558,19 +659,19 @@ class GpuStage:
         self.apply_growth(batch)
         if not batch.replay:
             self.set_tables(batch)
-            dev = self.device
-            for c in batch.ctx_lens:
-                if c + 1 > self.max_seq_len:
-                    raise ValueError("sequence exceeds max_seq_len")
-            up = lambda dst, vals, dt: dst.copy_(torch.tensor(vals, dtype=dt))
+            ctx = np.asarray(batch.ctx_lens, dtype=np.int32)
+            if B and int(ctx.max()) + 1 > self.max_seq_len:
+                raise ValueError("sequence exceeds max_seq_len")
             # rows whose q_len is 0 are padding: park them on the null slot
-            slots = [s if q == 1 else self.null_slot for s, q in zip(batch.slots, batch.q_lens)]
-            up(st.slots, slots, torch.int32); up(st.ctx, batch.ctx_lens, torch.int32)
-            up(st.temperature, batch.temperature, torch.float32); up(st.top_k, batch.top_k, torch.int32)
-            up(st.top_p, batch.top_p, torch.float32); up(st.seeds, batch.seeds, torch.int64)
-            up(st.steps, batch.sample_steps, torch.int32)
+            slots = np.where(np.asarray(batch.q_lens) == 1, np.asarray(batch.slots), self.null_slot).astype(np.int32)
+            parts = [slots, ctx, np.asarray(batch.top_k, dtype=np.int32), np.asarray(batch.sample_steps, dtype=np.int32),
+                     np.asarray(batch.temperature, dtype=np.float32), np.asarray(batch.top_p, dtype=np.float32),
+                     np.asarray(batch.seeds, dtype=np.int64)]
             if self.plan.has_embed and batch.token_ids is not None:
-                up(st.ids, batch.token_ids, torch.int32)
+                parts.append(np.asarray(batch.token_ids, dtype=np.int32))
+            if any(p_.size != B for p_ in parts):
+                raise ValueError("a fixed-shape decode step needs every per-row field for every row")
+            self._upload(parts, st.params)          # one asynchronous copy straight into the graph's static fields
             max_ctx = max(batch.ctx_lens) if batch.ctx_lens else 0
             st.splits_wanted = self._pick_splits(B, max_ctx)
         if x is not None:

@@ -510,6 +510,22 @@ void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, 
               steps.data_ptr<int>(), (int)R, (int)vocab, logits.stride(0), dp, di, cap, cur_stream());
 }
 
+// dst[rows[r], :] = src[r, :] (int32 table rows; rows outside dst are skipped)
+void scatter_rows(Tensor dst, const Tensor& rows, const Tensor& src) {
+  check_i32(dst, "dst"); check_i32(rows, "rows"); check_i32(src, "src");
+  DLIA_CHECK(dst.dim() == 2 && src.dim() == 2 && src.size(1) == dst.size(1) && rows.dim() == 1 && rows.numel() == src.size(0),
+             "scatter_rows: dst [R, C], rows [n], src [n, C]");
+  dlia_scatter_rows_i32(dst.data_ptr<int>(), rows.data_ptr<int>(), src.data_ptr<int>(), (int)rows.numel(), (int)dst.size(1),
+                        (int)dst.size(0), cur_stream());
+}
+
+// dst.flat[idx[i]] = val[i] (int32; indices outside dst are skipped)
+void scatter(Tensor dst, const Tensor& idx, const Tensor& val) {
+  check_i32(dst, "dst"); check_i32(idx, "idx"); check_i32(val, "val");
+  DLIA_CHECK(idx.dim() == 1 && val.dim() == 1 && idx.numel() == val.numel(), "scatter: idx [n], val [n]");
+  dlia_scatter_i32(dst.data_ptr<int>(), idx.data_ptr<int>(), val.data_ptr<int>(), (int)idx.numel(), (long)dst.numel(), cur_stream());
+}
+
 void advance(Tensor x, int64_t delta) {
   check_i32(x, "x");
   dlia_advance_i32(x.data_ptr<int>(), (int)x.numel(), (int)delta, cur_stream());
@@ -536,6 +552,8 @@ TORCH_LIBRARY(dlia, m) {
   m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
   m.def("sample(Tensor(a!) out_tokens, Tensor logits, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
   m.def("advance(Tensor(a!) x, int delta) -> ()");
+  m.def("scatter_rows(Tensor(a!) dst, Tensor rows, Tensor src) -> ()");
+  m.def("scatter(Tensor(a!) dst, Tensor idx, Tensor val) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
@@ -552,6 +570,8 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
   m.impl("paged_attention", &paged_attention);
   m.impl("sample", &sample);
   m.impl("advance", &advance);
+  m.impl("scatter_rows", &scatter_rows);
+  m.impl("scatter", &scatter);
 }
 
 TORCH_LIBRARY_IMPL(dlia, CompositeExplicitAutograd, m) {

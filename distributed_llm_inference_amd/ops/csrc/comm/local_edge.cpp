@@ -157,6 +157,9 @@ int dlia_ledge_wait(void* h, int token, int recv_side, void* stream) {
   return 0;
 }
 // the stage loop's view: one function per end, same signature as dlia_edge_wait
+// The stream sends run on (for timing events recorded behind a send).
+void* dlia_ledge_send_stream(void* h) { return static_cast<LocalEdge*>(h)->sstream; }
+
 int dlia_ledge_wait_send(void* h, int token, void* stream) { return dlia_ledge_wait(h, token, 0, stream); }
 int dlia_ledge_wait_recv(void* h, int token, void* stream) { return dlia_ledge_wait(h, token, 1, stream); }
 

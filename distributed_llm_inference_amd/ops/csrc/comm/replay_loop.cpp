@@ -6,8 +6,8 @@
 // entries: 4-byte host-to-device copies) -> hipGraphLaunch on the micro-batch's stream -> copy of the
 // token ids to pinned host memory on the same stream -> completion event -> result ring. Everything
 // else — prefill chunks, recompositions, control messages — is handed back to the Python loop
-// (runtime/head.py::head_main), which answers through the same queue so that results leave in
-// submission order and the result ring keeps its single producer.
+// (runtime/head.py::head_main), which answers through the same queue so that the result ring keeps
+// its single producer; results leave as their steps complete.
 //
 // The same loop serves a stage behind stage 0 of a multi-stage pipeline (dlia_stage_*): a replay
 // descriptor from the previous stage's ring -> block-table growth -> receive of the hidden states
@@ -69,6 +69,42 @@ struct Mb {
   int next = 0;
 };
 
+// ---- step timeline -----------------------------------------------------------------------------------
+// Every step this loop issues is bracketed by HIP timing events on the streams it runs on: when the
+// micro-batch's stream became free for it (e[0]), when its input had arrived and the graph started
+// (e[1]), when the graph ended (e[2]) and, on a stage that sends, when the send had left (e[3], on the
+// hop's stream). Completed steps are turned into spans on the host clock (CLOCK_MONOTONIC, the clock
+// Python's perf_counter reads): recv-wait = e[0]..e[1], compute = e[1]..e[2], send = e[2]..e[3], next to
+// the host time this loop spent enqueueing the step. The compute spans also give the stage's GPU-busy
+// time (union over overlapping micro-batch streams), which is what /metrics reports per stage. Python
+// reads the spans out for a Chrome trace; nobody has to: the ring of finished spans overwrites itself.
+constexpr int kOpenSteps = 256;                  // steps whose events have not all completed yet
+constexpr int kDoneSpans = 8192;                 // finished spans kept for read-out
+constexpr int kSpanDoubles = 9;                  // step id, micro-batch, rows, host0, host1, recv0, comp0, comp1, send1 (microseconds)
+
+struct StepRec {
+  int step_id = 0, mb = 0, rows = 0, anchor = 0;
+  int64_t host0_ns = 0, host1_ns = 0;
+  hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+struct Anchor { hipEvent_t ev = nullptr; int64_t host_ns = 0; };
+
+struct Timeline {
+  bool on = true;
+  hipStream_t astream = nullptr;                 // private stream the anchors are recorded on (always idle)
+  Anchor anchors[2]; int cur = 0; int64_t anchored_ns = 0;
+  std::vector<hipEvent_t> pool;
+  std::deque<StepRec> open;
+  std::vector<double> done; size_t done_head = 0, done_count = 0;   // ring of kDoneSpans x kSpanDoubles
+  uint64_t busy_ns = 0, recv_wait_ns = 0, send_ns = 0, dropped = 0, tokens = 0;
+  double busy_until_us = 0;
+};
+
+inline int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct Pending {                                 // a submitted step whose result has not left yet
   int step_id; int n; const int32_t* host; hipEvent_t ev;
 };
@@ -83,6 +119,9 @@ struct Loop {
   std::vector<uint8_t> out;
   uint64_t native_steps = 0, handed_up = 0;
   EdgeRef ein, eout;                             // stage loop only: the hop in, the hop out
+  hipStream_t out_stream = nullptr;              // stream the outgoing hop's transfers run on (null: unknown, no send spans)
+  int64_t handoff_in = -1;                       // > 0: hand the n-th replay step from now up to Python instead of serving it
+  Timeline tl;
   char err[256] = {0};
 };
 
@@ -92,13 +131,92 @@ int fail(Loop* l, const char* what, hipError_t e) {
 }
 #define HIPCHK(l, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(l, #expr, e_); } while (0)
 
-// Sends every result at the front of the queue whose event has completed. 0 ok, -1 error.
+// A device-clock anchor: an event on an idle private stream, completed at once, stamped with the host
+// clock. Renewed every few minutes so that event-to-event distances stay small numbers (float
+// milliseconds); the previous anchor stays valid for the steps that were opened under it.
+int tl_anchor(Loop* l) {
+  Timeline& t = l->tl;
+  if (!t.astream && hipStreamCreateWithFlags(&t.astream, hipStreamNonBlocking) != hipSuccess) return -1;
+  const int64_t n = now_ns();
+  if (t.anchors[t.cur].ev && n - t.anchored_ns < 300000000000LL) return 0;
+  const int nxt = t.anchors[t.cur].ev ? 1 - t.cur : t.cur;
+  Anchor& a = t.anchors[nxt];
+  if (!a.ev && hipEventCreate(&a.ev) != hipSuccess) return -1;
+  if (hipEventRecord(a.ev, t.astream) != hipSuccess || hipEventSynchronize(a.ev) != hipSuccess) return -1;
+  a.host_ns = now_ns();
+  t.cur = nxt; t.anchored_ns = a.host_ns;
+  return 0;
+}
+
+hipEvent_t tl_event(Timeline& t) {
+  if (!t.pool.empty()) { hipEvent_t e = t.pool.back(); t.pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+// Opens the record of a step about to be issued; null when the timeline is off or too many steps are open.
+StepRec* tl_open(Loop* l, int step_id, int mb, int rows, int live) {
+  Timeline& t = l->tl;
+  t.tokens += (uint64_t)(live > 0 ? live : 0);
+  if (!t.on) return nullptr;
+  if ((int)t.open.size() >= kOpenSteps || tl_anchor(l) != 0) { t.dropped++; return nullptr; }
+  t.open.emplace_back();
+  StepRec& r = t.open.back();
+  r.step_id = step_id; r.mb = mb; r.rows = rows; r.anchor = t.cur; r.host0_ns = now_ns();
+  return &r;
+}
+
+void tl_stamp(Loop* l, StepRec* r, int which, hipStream_t stream) {
+  if (!r) return;
+  hipEvent_t e = tl_event(l->tl);
+  if (e && hipEventRecord(e, stream) == hipSuccess) r->e[which] = e;
+  else if (e) l->tl.pool.push_back(e);
+}
+
+// Turns the steps whose events have all completed into spans; cheap when nothing is open.
+void tl_reap(Loop* l) {
+  Timeline& t = l->tl;
+  while (!t.open.empty()) {
+    StepRec& r = t.open.front();
+    bool ready = true;
+    for (int i = 3; i >= 0 && ready; --i)
+      if (r.e[i] && hipEventQuery(r.e[i]) == hipErrorNotReady) ready = false;
+    if (!ready) return;
+    const Anchor& a = t.anchors[r.anchor];
+    double at[4] = {-1, -1, -1, -1};
+    for (int i = 0; i < 4; ++i) {
+      float ms = 0.f;
+      if (r.e[i] && a.ev && hipEventElapsedTime(&ms, a.ev, r.e[i]) == hipSuccess) at[i] = (double)a.host_ns / 1e3 + (double)ms * 1e3;
+      if (r.e[i]) t.pool.push_back(r.e[i]);
+    }
+    if (at[1] >= 0 && at[2] >= at[1]) {            // GPU-busy time: union of the compute spans of all micro-batch streams
+      const double b = at[1] > t.busy_until_us ? at[1] : t.busy_until_us;
+      if (at[2] > b) { t.busy_ns += (uint64_t)((at[2] - b) * 1e3); t.busy_until_us = at[2]; }
+    }
+    if (at[0] >= 0 && at[1] >= at[0]) t.recv_wait_ns += (uint64_t)((at[1] - at[0]) * 1e3);
+    if (at[2] >= 0 && at[3] >= at[2]) t.send_ns += (uint64_t)((at[3] - at[2]) * 1e3);
+    if (t.done.empty()) t.done.resize((size_t)kDoneSpans * kSpanDoubles);
+    const size_t slot = (t.done_head + t.done_count) % kDoneSpans;
+    if (t.done_count == (size_t)kDoneSpans) { t.done_head = (t.done_head + 1) % kDoneSpans; t.dropped++; } else t.done_count++;
+    double* o = &t.done[slot * kSpanDoubles];
+    o[0] = r.step_id; o[1] = r.mb; o[2] = r.rows; o[3] = (double)r.host0_ns / 1e3; o[4] = (double)r.host1_ns / 1e3;
+    o[5] = at[0]; o[6] = at[1]; o[7] = at[2]; o[8] = at[3];
+    t.open.pop_front();
+  }
+}
+
+// Sends every queued result whose event has completed. Results carry their step id and the
+// scheduler matches them by it, so they leave as they complete, not in submission order: the tokens
+// of a decode step must not wait behind a prefill chunk of another micro-batch that was submitted
+// earlier and runs for longer (steps of ONE micro-batch share a stream and complete in order
+// anyway). 0 ok, -1 error.
 int drain(Loop* l, void* res_ring) {
-  while (!l->pending.empty()) {
-    Pending& p = l->pending.front();
+  for (auto it = l->pending.begin(); it != l->pending.end();) {
+    Pending& p = *it;
     if (p.ev) {
       hipError_t q = hipEventQuery(p.ev);
-      if (q == hipErrorNotReady) return 0;
+      if (q == hipErrorNotReady) { ++it; continue; }
       if (q != hipSuccess) return fail(l, "hipEventQuery", q);
     }
     const size_t bytes = 16 + (size_t)p.n * 4;
@@ -110,7 +228,7 @@ int drain(Loop* l, void* res_ring) {
       snprintf(l->err, sizeof(l->err), "result ring: put failed");
       return -1;
     }
-    l->pending.pop_front();
+    it = l->pending.erase(it);
   }
   return 0;
 }
@@ -169,10 +287,37 @@ int dlia_replay_push_external(void* h, int step_id, void* event, const void* hos
 
 int dlia_replay_pending(void* h) { return (int)static_cast<Loop*>(h)->pending.size(); }
 
-void dlia_replay_stats(void* h, uint64_t* out2) {
+// out8: steps served here, messages handed to Python, GPU-busy ns (union of compute spans), ns the
+// micro-batch streams waited for their input, ns from a step's end to its send's end, spans dropped,
+// tokens (live rows) of the steps served here, spans waiting to be read.
+void dlia_replay_stats(void* h, uint64_t* out8) {
   Loop* l = static_cast<Loop*>(h);
-  out2[0] = l->native_steps; out2[1] = l->handed_up;
+  tl_reap(l);
+  out8[0] = l->native_steps; out8[1] = l->handed_up; out8[2] = l->tl.busy_ns; out8[3] = l->tl.recv_wait_ns;
+  out8[4] = l->tl.send_ns; out8[5] = l->tl.dropped; out8[6] = l->tl.tokens; out8[7] = l->tl.done_count;
 }
+
+// Timeline on / off (on by default: a few event records per step).
+void dlia_replay_timeline(void* h, int on) { static_cast<Loop*>(h)->tl.on = on != 0; }
+
+// Pops up to `max_spans` finished spans into `out` (kSpanDoubles doubles each: step id, micro-batch,
+// rows, then microseconds on the CLOCK_MONOTONIC time base: host enqueue begin / end, stream free,
+// compute begin, compute end, send end; -1 where a stamp does not apply). Returns the count.
+int dlia_replay_read_spans(void* h, double* out, int max_spans) {
+  Loop* l = static_cast<Loop*>(h);
+  tl_reap(l);
+  Timeline& t = l->tl;
+  int n = 0;
+  while (n < max_spans && t.done_count > 0) {
+    memcpy(out + (size_t)n * kSpanDoubles, &t.done[t.done_head * kSpanDoubles], sizeof(double) * kSpanDoubles);
+    t.done_head = (t.done_head + 1) % kDoneSpans; t.done_count--; ++n;
+  }
+  return n;
+}
+
+// Test hook support: the n-th replay step from now (n >= 1) is handed up to Python instead of being
+// served here, so that a step-counting fault injector fires at the same step with or without this loop.
+void dlia_replay_handoff_in(void* h, long n) { static_cast<Loop*>(h)->handoff_in = n; }
 
 // Serves the descriptor ring until a message arrives that Python has to handle (returns 1, message
 // in msg_out / *len), `idle_ms` pass without one (0), or something fails (-1, dlia_replay_error; -2:
@@ -185,6 +330,7 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
   int idle_spins = 0, since_check = 0;
   for (;;) {
     if (drain(l, res_ring) != 0) return -1;
+    tl_reap(l);
     // back to the caller every idle_ms also under load, so that its heartbeat stays fresh while steps
     // never stop coming (queued results stay queued here and leave on the next call)
     if (idle_ms >= 0 && ++since_check >= 64) {
@@ -213,12 +359,14 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
       const Mb& m = l->mbs[d->mb];
       native = m.exec != nullptr && m.rows == d->rows && (d->ngrow == 0 || l->table != nullptr);
     }
+    if (native && l->handoff_in > 0 && --l->handoff_in == 0) { native = false; l->handoff_in = -1; }
     if (!native) {
       *len = (uint32_t)n;
       l->handed_up++;
       return 1;
     }
     Mb& m = l->mbs[d->mb];
+    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live);
     // block-table growth: table[slot][pos] = block, checked like the Python path (a bad entry is skipped)
     const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
     for (int i = 0; i < d->ngrow; ++i) {
@@ -230,10 +378,13 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
     }
     const int s = m.next; m.next = (m.next + 1) % kSlots;
     if (hipEventQuery(m.ev[s]) == hipErrorNotReady) HIPCHK(l, hipEventSynchronize(m.ev[s]));   // slot still in flight (never in practice)
+    tl_stamp(l, rec, 1, m.stream);
     HIPCHK(l, hipGraphLaunch(m.exec, m.stream));
+    tl_stamp(l, rec, 2, m.stream);
     HIPCHK(l, hipMemcpyAsync(m.host[s], m.tokens, (size_t)m.rows * 4, hipMemcpyDeviceToHost, m.stream));
     HIPCHK(l, hipEventRecord(m.ev[s], m.stream));
     l->pending.push_back(Pending{d->step_id, m.rows, m.host[s], m.ev[s]});
+    if (rec) rec->host1_ns = now_ns();
     l->native_steps++;
   }
 }
@@ -242,8 +393,9 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
 // The hops of this stage: `in` = the receiving end of the hop from the previous stage, `out` = the
 // sending end of the hop to the next stage (on the last stage: of the token feedback hop to stage 0).
 int dlia_stage_set_edges(void* h, void* in_h, void* in_recv, void* in_wait, void* in_err, void* out_h, void* out_send,
-                         void* out_wait, void* out_err) {
+                         void* out_wait, void* out_err, void* out_stream) {
   Loop* l = static_cast<Loop*>(h);
+  l->out_stream = (hipStream_t)out_stream;
   l->ein.h = in_h; l->ein.recv = (edge_recv_fn)in_recv; l->ein.wait = (edge_wait_fn)in_wait; l->ein.err = (edge_err_fn)in_err;
   l->eout.h = out_h; l->eout.send = (edge_send_fn)out_send; l->eout.wait = (edge_wait_fn)out_wait; l->eout.err = (edge_err_fn)out_err;
   return 0;
@@ -287,6 +439,7 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
   const auto t_enter = std::chrono::steady_clock::now();
   int idle_spins = 0, since_check = 0;
   for (;;) {
+    tl_reap(l);
     if (idle_ms >= 0 && ++since_check >= 64) {
       since_check = 0;
       if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_enter).count() >= idle_ms) {
@@ -310,6 +463,7 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
       const Mb& m = l->mbs[d->mb];
       native = m.exec != nullptr && m.rows == d->rows && m.in_ptr != nullptr && (d->ngrow == 0 || l->table != nullptr);
     }
+    if (native && l->handoff_in > 0 && --l->handoff_in == 0) { native = false; l->handoff_in = -1; }
     if (!native) {
       if (stage_flush(l) != 0) return -1;
       *len = (uint32_t)n;
@@ -317,6 +471,7 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
       return 1;
     }
     Mb& m = l->mbs[d->mb];
+    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live);
     const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
     for (int i = 0; i < d->ngrow; ++i) {
       const int slot = g[i], pos = g[d->ngrow + i], blk = g[2 * d->ngrow + i];
@@ -327,18 +482,23 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
     }
     // the receive overwrites the input buffer: after its previous reader (the stream's earlier work)
     const int rtok = l->ein.recv(l->ein.h, m.in_ptr, m.in_bytes, m.stream, nullptr);
+    tl_stamp(l, rec, 0, m.stream);                            // the stream is free for this step from here on
     if (rtok < 0 || l->ein.wait(l->ein.h, rtok, m.stream) != 0) return hop_fail(l, "receive", l->ein);
     if (m.send_tok >= 0) {                                    // the graph overwrites the output buffer: after its last send
       if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) return hop_fail(l, "wait for a send", l->eout);
       m.send_tok = -1;
     }
+    tl_stamp(l, rec, 1, m.stream);                            // input there, output buffer free: compute starts
     HIPCHK(l, hipGraphLaunch(m.exec, m.stream));
+    tl_stamp(l, rec, 2, m.stream);
     if (next_ring != nullptr && l->rput(next_ring, msg_out, (uint32_t)n, 5000) != 0) {   // descriptor first: the next stage posts its receive
       snprintf(l->err, sizeof(l->err), "next stage's descriptor ring: put failed");
       return -1;
     }
     m.send_tok = l->eout.send(l->eout.h, m.out_ptr, m.out_bytes, m.stream);
     if (m.send_tok < 0) return hop_fail(l, "send", l->eout);
+    if (l->out_stream != nullptr) tl_stamp(l, rec, 3, l->out_stream);
+    if (rec) rec->host1_ns = now_ns();
     l->native_steps++;
   }
 }
@@ -364,6 +524,11 @@ void dlia_replay_destroy(void* h) {
       if (m.ev[i]) (void)hipEventDestroy(m.ev[i]);
     }
   if (l->grow_stage) (void)hipHostFree(l->grow_stage);
+  for (StepRec& r : l->tl.open)
+    for (hipEvent_t e : r.e) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : l->tl.pool) (void)hipEventDestroy(e);
+  for (Anchor& a : l->tl.anchors) if (a.ev) (void)hipEventDestroy(a.ev);
+  if (l->tl.astream) (void)hipStreamDestroy(l->tl.astream);
   delete l;
 }
 

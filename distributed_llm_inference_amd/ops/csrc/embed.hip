@@ -37,7 +37,36 @@ __global__ void advance_kernel(int* x, int n, int delta) {
   if (i < n) x[i] += delta;
 }
 
+// Block-table maintenance from a step's staged metadata (one pinned upload per step, no per-slot
+// host copies): whole rows for sequences whose table is new to the stage, single entries for
+// sequences that grew by a block. Indices out of range are skipped, never written.
+__global__ void scatter_rows_kernel(int* __restrict__ dst, const int* __restrict__ rows, const int* __restrict__ src,
+                                    int nrows, int ncols, int dst_rows) {
+  const int r = blockIdx.x;
+  const int row = rows[r];
+  if (row < 0 || row >= dst_rows) return;
+  for (int c = threadIdx.x; c < ncols; c += blockDim.x) dst[(long)row * ncols + c] = src[(long)r * ncols + c];
+}
+
+__global__ void scatter_kernel(int* __restrict__ dst, const int* __restrict__ idx, const int* __restrict__ val, int n, long limit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = idx[i];
+  if (j >= 0 && j < limit) dst[j] = val[i];
+}
+
 }  // namespace dlia
+
+extern "C" void dlia_scatter_rows_i32(int* dst, const int* rows, const int* src, int nrows, int ncols, int dst_rows,
+                                      hipStream_t stream) {
+  if (nrows <= 0 || ncols <= 0) return;
+  hipLaunchKernelGGL(dlia::scatter_rows_kernel, dim3(nrows), dim3(64), 0, stream, dst, rows, src, nrows, ncols, dst_rows);
+}
+
+extern "C" void dlia_scatter_i32(int* dst, const int* idx, const int* val, int n, long limit, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(dlia::scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, idx, val, n, limit);
+}
 
 extern "C" void dlia_embed(void* out, const int* ids, const int* pos, const void* wte, const void* wpe,
                            int T, int H, int vocab, int max_pos, hipStream_t stream) {

@@ -93,5 +93,7 @@ void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
 
 // ---- misc.hip -------------------------------------------------------------------------
 void dlia_advance_i32(int* x, int n, int delta, hipStream_t stream);
+void dlia_scatter_rows_i32(int* dst, const int* rows, const int* src, int nrows, int ncols, int dst_rows, hipStream_t stream);
+void dlia_scatter_i32(int* dst, const int* idx, const int* val, int n, long limit, hipStream_t stream);
 
 }  // extern "C"

@@ -32,6 +32,7 @@ def _lib():
             "dlia_ledge_wait": (ci, [vp, ci, ci, vp]),
             "dlia_ledge_query": (ci, [vp, ci, ci]),
             "dlia_ledge_set_timeout": (None, [vp, ci]),
+            "dlia_ledge_send_stream": (vp, [vp]),
             "dlia_ledge_abort": (ci, [vp]),
             "dlia_ledge_close": (ci, [vp]),
         }
@@ -99,6 +100,10 @@ class LocalDeviceEdge(Edge):
         """(handle, send, recv, wait for a send, wait for a receive, last error text) for the native stage loop."""
         f = lambda name: C.cast(getattr(self.L, name), C.c_void_p)
         return self.h, f("dlia_ledge_send"), f("dlia_ledge_recv"), f("dlia_ledge_wait_send"), f("dlia_ledge_wait_recv"), f("dlia_ledge_last_error")
+
+    def native_send_stream(self) -> int:
+        """Handle of the HIP stream this hop's sends run on."""
+        return int(self.L.dlia_ledge_send_stream(self.h) or 0)
 
     def abort(self):
         if not self.closed:

@@ -20,11 +20,12 @@ and the orchestrator's relay loop (orchestration.py:109-137) with a true stage->
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import os
 import time
 import traceback
-from typing import Dict, List, Optional
+from typing import Deque, Dict, List, Optional
 
 import torch
 
@@ -50,6 +51,12 @@ class FaultInjector:
             self.rules.append((action, int(bits[0]), float(bits[1]) if len(bits) > 1 else 0.0))
         self.count = 0
 
+    def next_at(self) -> Optional[int]:
+        """Step count of the next rule still ahead (None: no rule left). The native loops serve
+        steps without entering Python; they hand exactly that step up so that it is counted here."""
+        ahead = [at for _, at, _ in self.rules if at > self.count]
+        return min(ahead) if ahead else None
+
     def tick(self):
         self.count += 1
         for action, at, arg in self.rules:
@@ -61,6 +68,63 @@ class FaultInjector:
                 time.sleep(arg)
             if action == "raise":
                 raise RuntimeError(f"injected fault at step {at}")
+
+
+class GpuSpans:
+    """Device-side timing of the steps the Python loop executes: HIP timing events recorded around a
+    step's wait for its input, its kernels and its send; completed steps become spans on the host
+    clock (Chrome trace) and the compute spans add up — as a union over the streams — to the stage's
+    GPU-busy time, which `/metrics` reports. The native loops keep the same books for the steps they
+    serve (`ops/csrc/comm/replay_loop.cpp`)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._open: Deque[tuple] = collections.deque()
+        self._anchor = None                    # (event, host ns)
+        self._astream = None
+        self.busy_ns = 0
+        self._busy_until_us = 0.0
+
+    def _anchored(self):
+        now = time.perf_counter_ns()
+        if self._anchor is None or now - self._anchor[1] > 300e9:
+            if self._astream is None:
+                self._astream = torch.cuda.Stream(device=self.device)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(self._astream)           # an idle private stream: completes at once
+            ev.synchronize()
+            self._anchor = (ev, time.perf_counter_ns())
+        return self._anchor
+
+    def stamp(self, stream=None) -> "torch.cuda.Event":
+        ev = torch.cuda.Event(enable_timing=True)      # (not pooled: adjacent spans share their boundary events)
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+        return ev
+
+    def add(self, track: str, name: str, e0, e1, args: Optional[dict] = None, busy: bool = False):
+        self._open.append((self._anchored(), track, name, e0, e1, args or {}, busy))
+
+    def reap(self, tracer=None, wait: bool = False) -> int:
+        """Resolves finished spans (all of them with `wait`); returns the GPU-busy ns they added."""
+        added = 0
+        while self._open:
+            (aev, ans), track, name, e0, e1, args, busy = self._open[0]
+            if wait:
+                e1.synchronize()
+            elif not e1.query():
+                break
+            self._open.popleft()
+            t0 = ans / 1e3 + aev.elapsed_time(e0) * 1e3
+            t1 = ans / 1e3 + aev.elapsed_time(e1) * 1e3
+            if busy and t1 > t0:
+                b = max(t0, self._busy_until_us)
+                if t1 > b:
+                    added += int((t1 - b) * 1e3)
+                    self._busy_until_us = t1
+            if tracer is not None:
+                tracer.span(track, name, int(t0 * 1e3), int(max(t0, t1) * 1e3), args)
+        self.busy_ns += added
+        return added
 
 
 class StageRuntime:
@@ -78,6 +142,10 @@ class StageRuntime:
         self.hidden = executor.spec.hidden_size
         self.act_dtype = torch.bfloat16 if self.on_gpu else getattr(executor, "dtype", torch.float32)
         self._send_pending: Dict[int, Handle] = {}     # micro-batch -> last send of its output buffer
+        # Sends out of eager steps leave from freshly allocated tensors. The caching allocator hands a
+        # freed block back to the stream it was allocated on (the eager stream) at once, so such a tensor
+        # is kept here until THAT stream has waited for its send: the next eager step does so first thing.
+        self._eager_sends: List[tuple] = []
         self._fb_bufs: Dict[tuple, torch.Tensor] = {}
         self._eager_in: Optional[torch.Tensor] = None
         self._local_fb: Dict[int, torch.Tensor] = {}   # single-stage pipeline: last tokens per micro-batch
@@ -92,7 +160,11 @@ class StageRuntime:
         self._main_stream = torch.cuda.current_stream(self.device) if self.on_gpu else None
         n = max(1, int(decode_streams)) if self.on_gpu and hasattr(executor, "decode_step") else 0
         self._decode_streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
-        self._eager_done = None           # event after the latest eager step (orders later decode steps)
+        # micro-batch -> event after its latest eager step: only that micro-batch's decode steps wait for it
+        self._eager_done: Dict[int, "torch.cuda.Event"] = {}
+        self._eager_barrier = os.environ.get("DLIA_EAGER_BARRIER") == "1"    # A/B: eager steps order against every micro-batch
+        self.spans = GpuSpans(self.device) if self.on_gpu else None
+        self._probe_stream = None         # tracing only: observes when a send has left without holding the compute stream up
 
     # ---- helpers ---------------------------------------------------------------------------
     def _graph_decode(self, desc: StepBatch) -> bool:
@@ -139,17 +211,31 @@ class StageRuntime:
         if desc.kind != KIND_STEP or not self.on_gpu:
             return self._execute(desc, fb_wait)
         s = self._stream_of(desc)
+        mb = desc.micro_batch
         with torch.cuda.stream(s):
             if s is self._main_stream:
-                # eager step: after the decode steps already queued for this micro-batch
-                for ds in self._decode_streams:
-                    s.wait_stream(ds)
+                # An eager step (a prefill chunk) shares nothing with the decode steps of OTHER micro-batches:
+                # it has its own workspace, writes the block-table rows and KV blocks of its own sequences
+                # only, and eager steps are ordered among themselves by this stream. So it waits for the
+                # decode steps already queued for its own micro-batch and nothing else; the graphs of the
+                # other micro-batches keep replaying next to it, and a chunk no longer stops every stream
+                # of the stage for its whole duration.
+                if self._eager_barrier:
+                    for ds in self._decode_streams:       # A/B switch: the chunk stops every stream of the stage
+                        s.wait_stream(ds)
+                elif self._decode_streams:
+                    s.wait_stream(self._decode_streams[mb % len(self._decode_streams)])
                 out = self._execute(desc, fb_wait)
-                self._eager_done = torch.cuda.Event()
-                self._eager_done.record(s)
+                ev = torch.cuda.Event()
+                ev.record(s)
+                if self._eager_barrier:
+                    self._eager_done = {m: ev for m in range(max(len(self._decode_streams), getattr(self.ex, "decode_states", 1)))}
+                else:
+                    self._eager_done[mb] = ev
             else:
-                if self._eager_done is not None:
-                    s.wait_event(self._eager_done)        # prefill of these sequences has run
+                ev = self._eager_done.pop(mb, None)
+                if ev is not None:
+                    s.wait_event(ev)                      # prefill of these sequences has run (later steps: stream order)
                 out = self._execute(desc, fb_wait)
         return out
 
@@ -170,6 +256,13 @@ class StageRuntime:
         self.fault.tick()
         mb, B, T = desc.micro_batch, desc.num_seqs, desc.num_tokens
         graph = self._graph_decode(desc)
+        sp, traced = self.spans, self.tracer is not None and self.spans is not None
+        span_args = {"mb": mb, "tokens": T, "decode": desc.is_decode, "step": desc.step_id, "loop": "python"}
+        e_free = sp.stamp() if traced else None        # the stream is free for this step from here on
+        if not graph and self._eager_sends:
+            for h, _keep in self._eager_sends:         # (stream-side waits on transfers that left long ago)
+                h.wait()
+            self._eager_sends.clear()
 
         # ---- input ----------------------------------------------------------------------
         x = None
@@ -189,6 +282,8 @@ class StageRuntime:
                         prev = self._local_fb.get(mb)
                         if prev is not None and prev.numel() == B:
                             x = prev
+                            if self.on_gpu:           # allocated by the eager stream, read by this one
+                                prev.record_stream(torch.cuda.current_stream(self.device))
                 elif L.num_stages == 1:
                     x = self._local_fb[mb]
                 else:
@@ -207,7 +302,9 @@ class StageRuntime:
         prev_send = self._send_pending.pop(mb, None)
         if prev_send is not None:
             prev_send.wait()          # the output buffer of this micro-batch is free again
-        gtok = self.tracer.gpu_begin() if (self.tracer is not None and self.on_gpu) else None
+        e_in = sp.stamp() if sp is not None else None   # input there, output buffer free: compute starts
+        if traced:
+            sp.add(f"stage{self.stage}.gpu.mb{mb}", "recv-wait", e_free, e_in, span_args)
         if graph:
             out = self.ex.decode_step(desc, x)
         else:
@@ -219,8 +316,10 @@ class StageRuntime:
             elif L.num_stages > 1:
                 out = out.clone()     # eager outputs alias a workspace the next step overwrites
 
-        if gtok is not None:
-            self.tracer.gpu_end(gtok, f"stage{self.stage}.gpu", "compute", {"mb": mb, "tokens": T})
+        e_out = None
+        if sp is not None:
+            e_out = sp.stamp()
+            sp.add(f"stage{self.stage}.gpu.mb{mb}", "compute", e_in, e_out, span_args, busy=True)
 
         # ---- output ----------------------------------------------------------------------
         result = None
@@ -230,12 +329,27 @@ class StageRuntime:
                 self._local_fb[mb] = out
             elif out.numel() > 0:
                 self._send_pending[mb] = L.fb_data.send(out)
+                if not graph and self.on_gpu:
+                    self._eager_sends.append((self._send_pending[mb], out))
         else:
             L.next_ctrl.put(desc.to_bytes())           # descriptor first: the next stage posts its recv
             self._send_pending[mb] = L.next_data.send(out)
+            if not graph and self.on_gpu:
+                self._eager_sends.append((self._send_pending[mb], out))
+        if traced and mb in self._send_pending and L.num_stages > 1:
+            # when the send has left: observed from a side stream, the compute stream is not held up
+            if self._probe_stream is None:
+                self._probe_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._probe_stream):
+                try:
+                    self._send_pending[mb].wait()
+                    sp.add(f"stage{self.stage}.hop-out", "send", e_out, sp.stamp(), span_args)
+                except Exception:
+                    pass
         self.steps += 1
         if self.board is not None:
-            self.board.beat(self.stage, 1, T, time.perf_counter_ns() - t_start)
+            # busy = GPU time of the steps that have completed since the last beat (HIP events), not host time
+            self.board.beat(self.stage, 1, T, sp.reap(self.tracer) if sp is not None else time.perf_counter_ns() - t_start)
         if self.tracer is not None:
             self.tracer.span(f"stage{self.stage}.host", "enqueue step", t_start, time.perf_counter_ns(),
                              {"mb": mb, "tokens": T, "decode": desc.is_decode})
@@ -279,6 +393,11 @@ class StageRuntime:
         """Stage 0 writes `trace_path` and folds in the files the other stages left next to it."""
         if self.tracer is None or not self.trace_path:
             return None
+        if self.spans is not None:
+            self.spans.reap(self.tracer, wait=True)
+        nl = getattr(self, "native_loop", None)
+        if nl is not None and getattr(nl, "h", None):
+            nl.feed_tracer(self.tracer, self.stage)
         from ..utils.tracing import stage_trace_path
         path = stage_trace_path(self.trace_path, self.stage)
         return self.tracer.dump(path, merge_glob=(self.trace_path + ".stage*") if self.stage == 0 else None)
@@ -313,6 +432,7 @@ class StageRuntime:
     def abort(self):
         """Abandon every hop of this stage (RCCL: ncclCommAbort) without waiting for the device."""
         self._send_pending.clear()
+        self._eager_sends.clear()
         self.links.abort()
 
 
@@ -326,7 +446,7 @@ def _native_stage_loop_for(runtime: StageRuntime):
     L, ex = runtime.links, runtime.ex
     edge_out = L.fb_data if L.is_last else L.next_data
     if not (runtime.on_gpu and L.num_stages > 1 and not L.is_first and hasattr(ex, "decode_step") and getattr(ex, "use_graphs", False)
-            and not runtime.debug_top5 and runtime.tracer is None and not runtime.fault.rules
+            and not runtime.debug_top5
             and hasattr(L.prev_ctrl, "ring") and (L.next_ctrl is None or hasattr(L.next_ctrl, "ring"))
             and hasattr(L.prev_data, "native_ends") and hasattr(edge_out, "native_ends")):
         return None
@@ -348,9 +468,9 @@ def _enter_native(runtime: StageRuntime):
         with torch.cuda.stream(s):
             h.wait()
     runtime._send_pending.clear()
-    if runtime._eager_done is not None:
-        for s in runtime._decode_streams:
-            s.wait_event(runtime._eager_done)
+    for mb, ev in list(runtime._eager_done.items()):
+        runtime._decode_streams[mb % len(runtime._decode_streams)].wait_event(ev)
+    runtime._eager_done.clear()
 
 
 def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s: float = 30.0) -> int:
@@ -364,21 +484,27 @@ def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s:
     if board is not None:
         board.set_state(runtime.stage, ST_READY)
     nl = None
-    counted = 0
+    counted = tokens_counted = busy_counted = 0
     try:
         nl = _native_stage_loop_for(runtime)
         runtime.native_loop = nl
         while True:
             if nl is not None:
                 _enter_native(runtime)
+                due = runtime.fault.next_at()               # a fault rule counts steps: the step it names runs in Python
+                nl.handoff_in(due - runtime.fault.count if due is not None else 0)
                 rc, msg = nl.serve(int(idle_beat_s * 1000))
-                n = nl.stats()["native_steps"]
+                st = nl.stats()
+                n = st["native_steps"]
                 if n > counted:
                     runtime.steps += n - counted
+                    runtime.fault.count += n - counted
                     runtime.ex.graph_replays += n - counted
                     if board is not None:
-                        board.beat(runtime.stage, n - counted, 0, 0)
-                    counted = n
+                        board.beat(runtime.stage, n - counted, st["tokens"] - tokens_counted, st["gpu_busy_ns"] - busy_counted)
+                    counted, tokens_counted, busy_counted = n, st["tokens"], st["gpu_busy_ns"]
+                if runtime.tracer is not None:
+                    nl.feed_tracer(runtime.tracer, runtime.stage)
                 if rc == -2:
                     break
                 if rc == 0:
@@ -418,6 +544,7 @@ def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s:
             pass
         if nl is not None:
             runtime.native_stats = nl.stats()
+            runtime.native_loop = None
             nl.close()
     if board is not None:
         board.set_state(runtime.stage, ST_STOPPED)

@@ -183,6 +183,10 @@ class RcclEdge(Edge):
         f = lambda name: C.cast(getattr(self.L, name), C.c_void_p)
         return self.h, f("dlia_edge_send"), f("dlia_edge_recv"), f("dlia_edge_wait"), f("dlia_edge_wait"), f("dlia_comm_last_error")
 
+    def native_send_stream(self) -> int:
+        """Handle of the HIP stream this hop's transfers run on."""
+        return int(self.L.dlia_edge_stream(self.h) or 0)
+
     # ---- lifecycle ---------------------------------------------------------------------------
     def stats(self):
         out = (C.c_uint64 * 4)()

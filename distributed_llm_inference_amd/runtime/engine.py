@@ -49,6 +49,32 @@ class EngineError(RuntimeError):
     pass
 
 
+class Histogram:
+    """Cumulative histogram with fixed upper bounds (seconds), in the shape Prometheus expects."""
+
+    def __init__(self, bounds):
+        self.bounds = list(bounds)
+        self.counts = [0] * (len(self.bounds) + 1)      # last: +Inf
+        self.total, self.n = 0.0, 0
+
+    def observe(self, v: float):
+        import bisect
+        self.counts[bisect.bisect_left(self.bounds, v)] += 1
+        self.total += v
+        self.n += 1
+
+    def snapshot(self):
+        cum, out = 0, []
+        for b, c in zip(self.bounds + [float("inf")], self.counts):
+            cum += c
+            out.append((b, cum))
+        return {"buckets": out, "sum": self.total, "count": self.n}
+
+
+TTFT_BOUNDS = (0.005, 0.01, 0.025, 0.05, 0.1, 0.25, 0.5, 1.0, 2.5, 5.0, 10.0, 30.0)
+ITL_BOUNDS = (0.001, 0.002, 0.004, 0.008, 0.016, 0.032, 0.064, 0.128, 0.256, 0.512, 1.0, 4.0)
+
+
 @dataclass
 class Request:
     rid: int
@@ -178,6 +204,8 @@ class Engine:
                       "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0, "rejected": 0, "rows_moved": 0}
         self.latencies: Deque[float] = collections.deque(maxlen=4096)     # per-token decode latencies (s)
         self.ttfts: Deque[float] = collections.deque(maxlen=1024)
+        self.hist_ttft = Histogram(TTFT_BOUNDS)          # arrival -> first token
+        self.hist_itl = Histogram(ITL_BOUNDS)            # gap between consecutive tokens of a request
 
     # ---- lifecycle -------------------------------------------------------------------------
     def start(self):
@@ -730,8 +758,10 @@ class Engine:
             if not r.t_first:               # (a re-prefill after a preemption keeps the first arrival)
                 r.t_first = now
                 self.ttfts.append(now - r.t_arrival)
+                self.hist_ttft.observe(now - r.t_arrival)
         elif r.token_times:
             self.latencies.append(now - r.token_times[-1])
+            self.hist_itl.observe(now - r.token_times[-1])
         if r.params.stop_on_eos and r.eos_id is not None and tok == r.eos_id:
             self._finish(r, now)          # EOS is not emitted (orchestration.py:181-183)
             return
@@ -776,4 +806,5 @@ class Engine:
         return {**self.stats, "waiting": len(self.waiting) + len(self._inbox),
                 "running": sum(len(mb.live()) for mb in self.mbs),
                 "kv_blocks_used": self.alloc.used, "kv_blocks_total": self.alloc.num_blocks,
-                "tpot_ms_p50": p(0.5), "tpot_ms_p99": p(0.99), "fatal": self.fatal}
+                "tpot_ms_p50": p(0.5), "tpot_ms_p99": p(0.99), "fatal": self.fatal,
+                "ttft_hist": self.hist_ttft.snapshot(), "itl_hist": self.hist_itl.snapshot()}

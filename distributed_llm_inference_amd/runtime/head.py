@@ -268,7 +268,7 @@ def _native_replay_for(runtime, cin, res):
         return None
     ex = runtime.ex
     if not (runtime.on_gpu and runtime.links.num_stages == 1 and hasattr(ex, "decode_step") and getattr(ex, "use_graphs", False)
-            and not runtime.debug_top5 and runtime.tracer is None and hasattr(cin, "ring") and hasattr(res, "ring")):
+            and not runtime.debug_top5 and hasattr(cin, "ring") and hasattr(res, "ring")):
         return None
     from .replay import NativeReplay
     dev = torch.device(runtime.device)
@@ -280,27 +280,34 @@ def _native_replay_for(runtime, cin, res):
 
 def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
     """`head_main` around the native loop: C++ serves replay steps, Python whatever else arrives;
-    Python's results join the native queue so they leave in submission order."""
+    Python's results join the native queue (one producer for the result ring)."""
     from collections import deque
     from ..parallel.shm import ST_ERROR, ST_READY, ST_STOPPED
     board, ex = runtime.board, runtime.ex
     keep = deque(maxlen=256)             # results (pinned buffers, events) referenced by the native queue
-    counted = 0
+    counted = tokens_counted = busy_counted = 0
+    runtime.native_loop = nr
 
     def account():
-        nonlocal counted
-        n = nr.stats()["native_steps"]
+        nonlocal counted, tokens_counted, busy_counted
+        st = nr.stats()
+        n = st["native_steps"]
         if n > counted:
             runtime.steps += n - counted
-            if board is not None:
-                board.beat(runtime.stage, n - counted, 0, 0)
-            counted = n
+            runtime.fault.count += n - counted
+            if board is not None:          # tokens and GPU-busy time (HIP events around the graphs) of the steps served natively
+                board.beat(runtime.stage, n - counted, st["tokens"] - tokens_counted, st["gpu_busy_ns"] - busy_counted)
+            counted, tokens_counted, busy_counted = n, st["tokens"], st["gpu_busy_ns"]
+        if runtime.tracer is not None:
+            nr.feed_tracer(runtime.tracer, runtime.stage)
 
     if board is not None:
         board.set_state(runtime.stage, ST_READY)
     step_id = -1
     try:
         while True:
+            due = runtime.fault.next_at()                   # a fault rule counts steps: the step it names runs in Python
+            nr.handoff_in(due - runtime.fault.count if due is not None else 0)
             rc, msg = nr.serve(int(idle_beat_s * 1000))
             account()
             if rc == -2:
@@ -346,6 +353,8 @@ def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
             if path:
                 with open(path, "w") as f:
                     json.dump(nr.stats(), f)
+            runtime.dump_trace()
+            runtime.native_loop = None
             nr.close()
         except Exception:
             pass
@@ -356,8 +365,8 @@ def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
 
 def head_main(runtime, cin, res, idle_beat_s: float = 0.5) -> int:
     """Loop of a stage-0 process serving a `RemoteHead`: descriptors in, token ids out, until
-    SHUTDOWN. A forwarder thread waits for each step's tokens (device event / feedback receive) in
-    submission order, so the descriptor loop itself never blocks on the device. A single-stage GPU
+    SHUTDOWN. A forwarder thread polls the submitted steps' tokens (device event / feedback receive)
+    and sends each result when it is there, so the descriptor loop itself never blocks on the device. A single-stage GPU
     pipeline runs the loop natively instead (`runtime/replay.py`)."""
     from ..parallel.shm import ST_ERROR, ST_READY, ST_STOPPED, RingClosed
     head = LocalHead(runtime)
@@ -374,21 +383,38 @@ def head_main(runtime, cin, res, idle_beat_s: float = 0.5) -> int:
             res.put(msg)
 
     def forward():
+        # Results leave as their steps complete (the scheduler matches them by step id): a decode
+        # step's tokens do not wait behind an earlier, longer prefill chunk of another micro-batch.
+        waiting = []
+        closing = False
         while True:
-            item = pending.get()
-            if item is None:
-                return
-            step_id, r = item
             try:
-                reply(pack_result(step_id, r.get()))
-            except BaseException as e:          # reported to the scheduler, which fails the requests
-                failed.set()
-                if board is not None:
-                    board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
+                item = pending.get(timeout=None if not waiting else 50e-6)
+                if item is None:
+                    closing = True
+                else:
+                    waiting.append(item)
+                    continue                      # take everything that is queued before polling
+            except queue.Empty:
+                pass
+            still = []
+            for step_id, r in waiting:
                 try:
-                    reply(pack_result(step_id, [], f"{type(e).__name__}: {e}"))
-                except Exception:
-                    pass
+                    if not closing and not r.ready():
+                        still.append((step_id, r))
+                        continue
+                    reply(pack_result(step_id, r.get()))
+                except BaseException as e:          # reported to the scheduler, which fails the requests
+                    failed.set()
+                    if board is not None:
+                        board.set_state(runtime.stage, ST_ERROR, f"{type(e).__name__}: {e}")
+                    try:
+                        reply(pack_result(step_id, [], f"{type(e).__name__}: {e}"))
+                    except Exception:
+                        pass
+                    return
+            waiting = still
+            if closing:
                 return
 
     th = threading.Thread(target=forward, name="dlia-head-results", daemon=True)

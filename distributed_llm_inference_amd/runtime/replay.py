@@ -29,7 +29,10 @@ def _lib():
             "dlia_replay_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
             "dlia_replay_flush": (ci, [vp, vp, ci]),
             "dlia_replay_destroy": (None, [vp]),
-            "dlia_stage_set_edges": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+            "dlia_stage_set_edges": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+            "dlia_replay_timeline": (None, [vp, ci]),
+            "dlia_replay_read_spans": (ci, [vp, C.POINTER(C.c_double), ci]),
+            "dlia_replay_handoff_in": (None, [vp, C.c_long]),
             "dlia_stage_set_mb": (ci, [vp, ci, vp, vp, vp, C.c_size_t, vp, C.c_size_t, ci]),
             "dlia_stage_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
         }
@@ -44,7 +47,53 @@ class NativeReplayError(RuntimeError):
     pass
 
 
-class NativeReplay:
+SPAN_FIELDS = ("step_id", "mb", "rows", "host0_us", "host1_us", "free_us", "compute0_us", "compute1_us", "send1_us")
+
+
+class _LoopCommon:
+    """What both native loops share: counters, the step timeline, the fault-injection hand-off."""
+
+    def stats(self):
+        out = (C.c_uint64 * 8)()
+        self.L.dlia_replay_stats(self.h, out)
+        return {"native_steps": int(out[0]), "handed_to_python": int(out[1]), "gpu_busy_ns": int(out[2]),
+                "recv_wait_ns": int(out[3]), "send_ns": int(out[4]), "spans_dropped": int(out[5]), "tokens": int(out[6]),
+                "spans_waiting": int(out[7])}
+
+    def timeline(self, on: bool):
+        self.L.dlia_replay_timeline(self.h, 1 if on else 0)
+
+    def read_spans(self, max_spans: int = 4096):
+        """Finished steps of this loop as dictionaries (`SPAN_FIELDS`; times in microseconds of the
+        host's monotonic clock — the clock `time.perf_counter_ns` reads; -1 where a stamp does not
+        apply). Each span is returned once."""
+        n_f = len(SPAN_FIELDS)
+        buf = (C.c_double * (max_spans * n_f))()
+        n = self.L.dlia_replay_read_spans(self.h, buf, max_spans)
+        return [dict(zip(SPAN_FIELDS, buf[i * n_f:(i + 1) * n_f])) for i in range(n)]
+
+    def handoff_in(self, n: int):
+        """The n-th replay step from now goes to Python instead of being served natively (n <= 0: never)."""
+        self.L.dlia_replay_handoff_in(self.h, int(n))
+
+    def feed_tracer(self, tracer, stage: int):
+        """Moves the finished spans into a Chrome-trace `Tracer`: enqueue (host), recv-wait, compute, send."""
+        if tracer is None:
+            return
+        for sp in self.read_spans():
+            args = {"mb": int(sp["mb"]), "rows": int(sp["rows"]), "step": int(sp["step_id"]), "loop": "native"}
+            ns = lambda k: int(sp[k] * 1e3)
+            if sp["host1_us"] >= sp["host0_us"] > 0:
+                tracer.span(f"stage{stage}.host", "enqueue step", ns("host0_us"), ns("host1_us"), args)
+            if sp["free_us"] >= 0 and sp["compute0_us"] >= sp["free_us"]:
+                tracer.span(f"stage{stage}.gpu.mb{int(sp['mb'])}", "recv-wait", ns("free_us"), ns("compute0_us"), args)
+            if sp["compute0_us"] >= 0 and sp["compute1_us"] >= sp["compute0_us"]:
+                tracer.span(f"stage{stage}.gpu.mb{int(sp['mb'])}", "compute", ns("compute0_us"), ns("compute1_us"), args)
+            if sp["send1_us"] >= 0 and sp["send1_us"] >= sp["compute1_us"] >= 0:
+                tracer.span(f"stage{stage}.hop-out", "send", ns("compute1_us"), ns("send1_us"), args)
+
+
+class NativeReplay(_LoopCommon):
     """`cin` / `res`: the `ShmRing`s of the descriptor and result rings (this process consumes the
     first and is the only producer of the second)."""
 
@@ -84,18 +133,13 @@ class NativeReplay:
     def flush(self, timeout_s: float = 30.0) -> bool:
         return self._check(self.L.dlia_replay_flush(self.h, self.res._h, int(timeout_s * 1000)), "flush") == 0
 
-    def stats(self):
-        out = (C.c_uint64 * 2)()
-        self.L.dlia_replay_stats(self.h, out)
-        return {"native_steps": int(out[0]), "handed_to_python": int(out[1])}
-
     def close(self):
         if self.h:
             self.L.dlia_replay_destroy(self.h)
             self.h = None
 
 
-class NativeStageLoop:
+class NativeStageLoop(_LoopCommon):
     """The native loop of a stage behind stage 0: replay descriptors from the previous stage's ring
     -> receive -> hipGraphLaunch -> descriptor on -> send, without entering Python. `prev_ring` /
     `next_ring`: `ShmRing`s (`next_ring` None on the last stage); `edge_in` / `edge_out`: hop objects
@@ -113,7 +157,8 @@ class NativeStageLoop:
             raise NativeReplayError("cannot create the native stage loop")
         ih, _, irecv, _, iwait, ierr = edge_in.native_ends()
         oh, osend, _, owait, _, oerr = edge_out.native_ends()
-        self.L.dlia_stage_set_edges(self.h, ih, irecv, iwait, ierr, oh, osend, owait, oerr)
+        out_stream = edge_out.native_send_stream() if hasattr(edge_out, "native_send_stream") else 0
+        self.L.dlia_stage_set_edges(self.h, ih, irecv, iwait, ierr, oh, osend, owait, oerr, C.c_void_p(out_stream))
         self._keep = (edge_in, edge_out)
         self._buf = C.create_string_buffer(prev_ring.slot_bytes)
         self._len = C.c_uint32(0)
@@ -141,11 +186,6 @@ class NativeStageLoop:
                                                  self._buf, self.prev_ring.slot_bytes, C.byref(self._len), idle_ms),
                          "native stage loop")
         return rc, (self._buf.raw[:self._len.value] if rc == 1 else None)
-
-    def stats(self):
-        out = (C.c_uint64 * 2)()
-        self.L.dlia_replay_stats(self.h, out)
-        return {"native_steps": int(out[0]), "handed_to_python": int(out[1])}
 
     def close(self):
         if self.h:

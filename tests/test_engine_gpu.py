@@ -632,3 +632,80 @@ def test_a_stage_process_dying_behind_native_rccl_hops_is_answered_and_replaced(
         assert not any(pid_alive(p) for p in old_pids)
     finally:
         b.close()
+
+
+def test_trace_shows_the_four_span_kinds_per_stage_with_the_native_loops_on(tmp_path):
+    """`trace_path` on an in-process 3-stage pipeline: the stages behind stage 0 keep serving replay
+    steps from their native loop (a tracer used to switch it off), and the Chrome trace holds, per
+    stage, the host's "enqueue step" and the device's recv-wait / compute / send spans — from HIP
+    events recorded inside the native loop for the steps it served, from the Python loop for the rest."""
+    import json
+    path = str(tmp_path / "trace.json")
+    pipe = LocalPipeline(cfg(pp_size=3, num_micro_batches=4, max_seq_len=256, trace_path=path))
+    try:
+        reqs = [pipe.engine.submit(p, greedy(24)) for p in prompts(12, seed=5)]
+        assert all(len(r.wait(300).output) == 24 for r in reqs)
+        pipe.engine.wait_idle()
+    finally:
+        pipe.close()
+    stats = [getattr(rt, "native_stats", None) for rt in pipe.runtimes[1:]]
+    assert all(st is not None and st["native_steps"] > 10 for st in stats), stats
+    ev = json.load(open(path))["traceEvents"]
+    spans = [e for e in ev if e.get("ph") == "X"]
+    for stage in (0, 1, 2):
+        mine = [e for e in spans if e["cat"].startswith(f"stage{stage}.")]
+        kinds = {e["name"] for e in mine}
+        assert {"enqueue step", "recv-wait", "compute", "send"} <= kinds, (stage, kinds)
+        assert all(e["dur"] >= 0 and e["ts"] > 0 for e in mine)
+    native = [e for e in spans if e["args"].get("loop") == "native"]
+    assert {e["name"] for e in native} >= {"enqueue step", "recv-wait", "compute", "send"}
+    # a stage's compute spans of one micro-batch do not overlap, and lie inside the run
+    for stage in (1, 2):
+        by_mb = {}
+        for e in spans:
+            if e["cat"].startswith(f"stage{stage}.gpu.mb") and e["name"] == "compute":
+                by_mb.setdefault(e["cat"], []).append((e["ts"], e["ts"] + e["dur"]))
+        comp = sorted(max(by_mb.values(), key=len))
+        assert len(comp) > 5 and all(a[1] <= b[0] + 50 for a, b in zip(comp, comp[1:])), comp[:4]
+
+
+def test_gpu_busy_time_per_stage_comes_from_the_device_also_under_the_native_loops():
+    """The status board's busy time per stage is GPU time (HIP events around every step), also for
+    the steps the native loops serve: positive, and not more than the wall time of the run."""
+    import time
+    pipe = LocalPipeline(cfg(pp_size=2, num_micro_batches=3, max_seq_len=256))
+    try:
+        t0 = time.perf_counter()
+        reqs = [pipe.engine.submit(p, greedy(48)) for p in prompts(16, seed=9)]
+        assert all(len(r.wait(300).output) == 48 for r in reqs)
+        pipe.engine.wait_idle()
+        time.sleep(0.7)                       # the stage loops report at their next idle beat
+        wall_ns = (time.perf_counter() - t0) * 1e9
+        recs = [pipe.board.read(s) for s in range(2)]
+        from distributed_llm_inference_amd.serving.metrics import render
+        text = render(pipe.engine.snapshot(), pipe.board, 2)
+    finally:
+        pipe.close()
+    for r in recs:
+        assert 0 < r["busy_ns"] < wall_ns and r["tokens"] > 0, recs
+    assert "dlia_stage_busy_seconds_total" in text and "dlia_time_to_first_token_seconds_bucket" in text
+    assert "dlia_inter_token_latency_seconds_count" in text
+
+
+def test_a_step_counting_fault_fires_at_its_step_with_the_native_loop_serving(monkeypatch):
+    """Fault injection no longer switches the native stage loop off: the loop serves the replay steps
+    before the named one, hands that one to Python, the rule fires there — the failure path the
+    tests exercise is the one `serve` runs."""
+    pipe = LocalPipeline(cfg(pp_size=2, num_micro_batches=2, max_seq_len=256, fault_inject="stage1:raise@25", hop_timeout_s=5))
+    try:
+        r = pipe.engine.submit(prompts(1, seed=2)[0], greedy(64))
+        r.wait(120)
+        assert r.state == "failed" and pipe.engine.fatal, (r.error, pipe.engine.fatal)
+        rec = pipe.board.read(1)
+        assert rec["state"] == "error" and "injected fault at step 25" in rec["error"], rec
+        rt = pipe.runtimes[1]
+        assert rt.fault.count == 25
+        st = getattr(rt, "native_stats", None)
+        assert st is not None and st["native_steps"] >= 15, st
+    finally:
+        pipe.close()
