@@ -80,6 +80,8 @@ class _Work:
     xs: Optional[torch.Tensor]       # fp32 [T]         their per-row scales
     head_x: Optional[torch.Tensor]   # bf16 [B, H]      (last stage)
     logits: Optional[torch.Tensor]   # fp32 [B, vocab_pad]
+    cmax: Optional[torch.Tensor] = None   # fp32 [B, vocab_pad / 32]: maxima of the logits' 32-column chunks (large-M lm_head)
+    guided: bool = False             # the latest lm_head over this workspace left chunk maxima for the sampler
 
 
 @dataclass
@@ -129,6 +131,7 @@ class GpuStage:
             raise ValueError("kv_dtype must be bf16 or fp8")
         self.kv8 = kv_dtype == "fp8"
         self.decode_rows = int(decode_rows if decode_rows is not None else os.environ.get("DLIA_DECODE_ROWS", DEFAULT_DECODE_ROWS))
+        self._guided_ok = os.environ.get("DLIA_GUIDED_SAMPLER", "1") != "0"      # A/B switch: 0 = the sampler reads whole rows
         self.K = ops.load()
         # decoder-layer GEMMs: "fp8" = e4m3 weights (per-channel scale) x e4m3 activations (per-row
         # dynamic scale) on the block-scaled fp8 MFMA; "fp8w" = e4m3 weights widened to bf16 in
@@ -242,7 +245,8 @@ class GpuStage:
             xq=z(rows, max(s.hidden_size, s.q_size, s.intermediate_size), dt=torch.uint8) if self.wmode == "fp8" else None,
             xs=z(rows, dt=torch.float32) if self.wmode == "fp8" else None,
             head_x=z(B, s.hidden_size) if self.plan.has_head else None,
-            logits=z(B, self.vocab_pad, dt=torch.float32) if self.plan.has_head else None)
+            logits=z(B, self.vocab_pad, dt=torch.float32) if self.plan.has_head else None,
+            cmax=z(B, (self.vocab_pad + 255) // 256 * 8, dt=torch.float32) if self.plan.has_head and B > self.decode_rows else None)
 
     def _pack(self, p: Dict[str, torch.Tensor], name: str, w: torch.Tensor):
         """Packs one GEMM weight into MFMA-fragment order; fp8 mode also stores `<name>_s` scales.
@@ -510,7 +514,13 @@ class GpuStage:
         else:
             K.norm(hx, wk.h[:T], None, wk.ws, pend[0], pend[1], self.final_norm_w, self.final_norm_b,
                    rows_idx[:R], s.norm_eps, nmode)
-        K.gemm(wk.logits[:R], hx, self.lm_head, None, None, wk.ws, self.vocab_pad, 0, 0, 0)
+        # More than `decode_rows` rows: the tiled GEMM also leaves the maximum of every 32-column chunk of every
+        # row, and the sampler reads the logits only where a top-k candidate can be (a few KB of a 513 KB row).
+        wk.guided = wk.cmax is not None and R > self.decode_rows and s.vocab_size <= 131072 and self._guided_ok
+        if wk.guided:
+            K.gemm_head(wk.logits[:R], wk.cmax[:R], hx, self.lm_head, wk.ws, self.vocab_pad, s.vocab_size)
+        else:
+            K.gemm(wk.logits[:R], hx, self.lm_head, None, None, wk.ws, self.vocab_pad, 0, 0, 0)
         return wk.logits[:R]
 
     # ---- generic (eager) forward: prefill chunks, and decode when graphs are off ---------
@@ -595,7 +605,10 @@ class GpuStage:
                                                               pick(batch.top_p, np.float32), pick(batch.sample_steps, np.int32),
                                                               pick(batch.seeds, np.int64)])
         lg = self.wk0.logits[:R]  # `logits` is a view of this buffer (padded columns ignored by `vocab`)
-        self.K.sample(out, lg, temp, top_k, top_p, seeds, steps, self.spec.vocab_size, None, None)
+        if self.wk0.guided:
+            self.K.sample_guided(out, lg, self.wk0.cmax[:R], temp, top_k, top_p, seeds, steps, self.spec.vocab_size, None, None)
+        else:
+            self.K.sample(out, lg, temp, top_k, top_p, seeds, steps, self.spec.vocab_size, None, None)
         return out
 
     # ---- graph-captured decode ------------------------------------------------------------
@@ -632,8 +645,12 @@ class GpuStage:
         pend = self._layers(wk, B, B, st.ctx, st.slots, self._arange[:B + 1], st.ctx, st.slots, 1, st.splits)
         if self.plan.has_head:
             self._head(wk, self._arange, B, B, pend)
-            K.sample(st.tokens, wk.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
-                     self.spec.vocab_size, None, None)
+            if wk.guided:
+                K.sample_guided(st.tokens, wk.logits[:B], wk.cmax[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
+                                self.spec.vocab_size, None, None)
+            else:
+                K.sample(st.tokens, wk.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
+                         self.spec.vocab_size, None, None)
             K.advance(st.steps, 1)
             if self.plan.has_embed:
                 st.ids.copy_(st.tokens)      # single-stage pipeline: the feedback hop is local

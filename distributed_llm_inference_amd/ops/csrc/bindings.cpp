@@ -483,9 +483,9 @@ void paged_attention8(Tensor out, const Tensor& qkv, const Tensor& kv_cache, con
   paged_attention_impl(out, qkv, kv_cache, kv_scale, q_start, ctx_lens, block_table, slots, partial, max_q_len, Hq, Hkv, D, scale, splits);
 }
 
-void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, const Tensor& top_k,
-            const Tensor& top_p, const Tensor& seeds, const Tensor& steps, int64_t vocab,
-            OptTensor dbg_probs, OptTensor dbg_ids) {
+static void sample_impl(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, const Tensor& top_k,
+                        const Tensor& top_p, const Tensor& seeds, const Tensor& steps, int64_t vocab,
+                        OptTensor dbg_probs, OptTensor dbg_ids, OptTensor chunk_max) {
   check_i32(out_tokens, "out_tokens"); check_dev(logits, "logits");
   DLIA_CHECK(logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1, "logits must be fp32 [R, >=vocab]");
   const int64_t R = logits.size(0);
@@ -505,9 +505,59 @@ void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, 
     dp = dbg_probs->data_ptr<float>(); di = dbg_ids->data_ptr<int>(); cap = (int)dbg_probs->size(1);
     DLIA_CHECK(cap <= 1024, "dbg capacity <= 1024");
   }
+  const float* cm = nullptr; long ldc = 0;
+  if (chunk_max.has_value()) {
+    // one maximum per 32-column chunk of each row, as gemm_head writes them
+    check_dev(*chunk_max, "chunk_max");
+    DLIA_CHECK(chunk_max->scalar_type() == at::kFloat && chunk_max->dim() == 2 && chunk_max->stride(1) == 1 &&
+               chunk_max->size(0) >= R && chunk_max->size(1) >= (vocab + 31) / 32, "chunk_max must be fp32 [R, ceil(vocab / 32)]");
+    cm = chunk_max->data_ptr<float>(); ldc = chunk_max->stride(0);
+  }
   dlia_sample(out_tokens.data_ptr<int>(), logits.data_ptr<float>(), temperature.data_ptr<float>(),
               top_k.data_ptr<int>(), top_p.data_ptr<float>(), reinterpret_cast<const uint64_t*>(seeds.data_ptr<int64_t>()),
-              steps.data_ptr<int>(), (int)R, (int)vocab, logits.stride(0), dp, di, cap, cur_stream());
+              steps.data_ptr<int>(), (int)R, (int)vocab, logits.stride(0), dp, di, cap, cur_stream(), cm, ldc);
+}
+
+void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, const Tensor& top_k,
+            const Tensor& top_p, const Tensor& seeds, const Tensor& steps, int64_t vocab,
+            OptTensor dbg_probs, OptTensor dbg_ids) {
+  sample_impl(out_tokens, logits, temperature, top_k, top_p, seeds, steps, vocab, dbg_probs, dbg_ids, c10::nullopt);
+}
+
+// The same with the chunk maxima of `gemm_head`: the kernel reads the row only where a candidate can be.
+void sample_guided(Tensor out_tokens, const Tensor& logits, const Tensor& chunk_max, const Tensor& temperature,
+                   const Tensor& top_k, const Tensor& top_p, const Tensor& seeds, const Tensor& steps, int64_t vocab,
+                   OptTensor dbg_probs, OptTensor dbg_ids) {
+  sample_impl(out_tokens, logits, temperature, top_k, top_p, seeds, steps, vocab, dbg_probs, dbg_ids, chunk_max);
+}
+
+// lm_head for more than 256 rows: logits[M, N] (fp32) = x[M, K] @ Wp^T, and chunk_max[M, ceil(N / 32)] = the maximum of
+// every 32-column chunk of every row over the columns < vocab (the sampler's guide). `workspace` as for gemm.
+void gemm_head(Tensor logits, Tensor chunk_max, const Tensor& x, const Tensor& wp, OptTensor workspace, int64_t N,
+               int64_t vocab) {
+  check_bf16(x, "x"); check_rows(x, "x"); check_dev(logits, "logits"); check_dev(wp, "wp"); check_dev(chunk_max, "chunk_max");
+  const int64_t M = x.size(0), K = x.size(1);
+  DLIA_CHECK(M > 256, "gemm_head is the large-M lm_head (use gemm + sample below 257 rows)");
+  DLIA_CHECK(K % 128 == 0 && N % 4 == 0 && vocab > 0 && vocab <= N, "gemm_head: K % 128, N % 4, 0 < vocab <= N");
+  const int64_t n_pad = (N + 127) / 128 * 128;
+  DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == n_pad * K * 2, "packed weight size");
+  DLIA_CHECK(reinterpret_cast<uintptr_t>(wp.data_ptr()) % 16 == 0, "packed weight alignment");
+  DLIA_CHECK(logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1 && logits.size(0) >= M &&
+             logits.size(1) >= N && logits.stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(logits.data_ptr()) % 16 == 0,
+             "logits must be fp32 [M, >= N], 16-byte aligned rows");
+  // the kernel stores a maximum for every chunk of every 256-column block it computes
+  const int64_t chunks = (n_pad + 255) / 256 * 8;
+  DLIA_CHECK(chunk_max.scalar_type() == at::kFloat && chunk_max.dim() == 2 && chunk_max.stride(1) == 1 &&
+             chunk_max.size(0) >= M && chunk_max.size(1) >= chunks, "chunk_max must be fp32 [M, >= ", chunks, "]");
+  float* wsp = nullptr; int64_t wsn = 0;
+  if (workspace.has_value()) {
+    check_f32(*workspace, "workspace");
+    DLIA_CHECK(workspace->is_contiguous(), "gemm workspace must be contiguous");
+    wsp = workspace->data_ptr<float>(); wsn = workspace->numel();
+  }
+  dlia_gemm_large(logits.data_ptr(), x.data_ptr(), wp.data_ptr(), nullptr, nullptr, wsp, wsn, (int)M, (int)N, (int)K,
+                  x.stride(0), logits.stride(0), 0, 0, 1, 0, cur_stream(), chunk_max.data_ptr<float>(), chunk_max.stride(0),
+                  (int)vocab);
 }
 
 // dst[rows[r], :] = src[r, :] (int32 table rows; rows outside dst are skipped)
@@ -551,6 +601,8 @@ TORCH_LIBRARY(dlia, m) {
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
   m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
   m.def("sample(Tensor(a!) out_tokens, Tensor logits, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
+  m.def("sample_guided(Tensor(a!) out_tokens, Tensor logits, Tensor chunk_max, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
+  m.def("gemm_head(Tensor(a!) logits, Tensor(b!) chunk_max, Tensor x, Tensor wp, Tensor? workspace, int N, int vocab) -> ()");
   m.def("advance(Tensor(a!) x, int delta) -> ()");
   m.def("scatter_rows(Tensor(a!) dst, Tensor rows, Tensor src) -> ()");
   m.def("scatter(Tensor(a!) dst, Tensor idx, Tensor val) -> ()");
@@ -569,6 +621,8 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
   m.impl("norm_q", &norm_q);
   m.impl("paged_attention", &paged_attention);
   m.impl("sample", &sample);
+  m.impl("sample_guided", &sample_guided);
+  m.impl("gemm_head", &gemm_head);
   m.impl("advance", &advance);
   m.impl("scatter_rows", &scatter_rows);
   m.impl("scatter", &scatter);

@@ -22,6 +22,10 @@ struct GemmParams {
   int partial_only;           // write fp32 partials even when splitk == 1 (a consumer kernel sums them)
   int group_n;                // gemm_rows.hip only: column blocks per workgroup-order group (set by its launcher)
   int* counters;              // gemm_pingpong.hip with splitk > 1: one arrival counter per output tile, zero between launches
+  // gemm_pingpong.hip as the lm_head: besides the fp32 logits, the maximum of every 32-column chunk of every
+  // row (columns >= n_valid excluded) -> chunk_max[m * ldc + n / 32]; the sampler then reads only the chunks
+  // that can hold a top-k candidate instead of the whole row. Null: not wanted.
+  float* chunk_max = nullptr; long ldc = 0; int n_valid = 0;
 };
 
 __device__ __forceinline__ void store4(void* out, long ldo, int m, int n, const float (&v)[4], int out_f32) {

@@ -366,6 +366,31 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
           for (int j = 0; j < 2; ++j) acc[hm][hn][i][j] *= xs;
       }
   }
+  if (p.chunk_max != nullptr) {
+    // ---- lm_head: maximum of each 32-column chunk of each row ------------------------------------
+    // A wave holds, per row half and column half, 64 rows x 32 columns: lane (l15, quad) has row
+    // i * 16 + l15 and columns (j * 16 + quad * 4 + reg) of them. Eight values per lane, then a max over
+    // the four quads (lanes 16 and 32 apart), and the quad whose number equals (i & 3) stores the value.
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+      for (int hn = 0; hn < 2; ++hn) {
+        const int col0 = (cb * 16 + hn * 8 + wc * 2) * 16 + quad * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = -__builtin_inff();
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (col0 + j * 16 + r < p.n_valid) v = fmaxf(v, acc[hm][hn][i][j][r]);
+          v = fmaxf(v, __shfl_xor(v, 16, 64));
+          v = fmaxf(v, __shfl_xor(v, 32, 64));
+          const int m = mrow0 + hm * 128 + wr * 64 + i * 16 + l15;
+          if (quad == (i & 3) && m < p.M) p.chunk_max[(long)m * p.ldc + (cb * 8 + hn * 4 + wc)] = v;
+        }
+      }
+  }
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -426,13 +451,15 @@ static void launch_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
 extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream) { launch_pingpong<false>(p, stream); }
 
 // out[M,N] = epi(x[M,K] @ Wp^T) for bf16 weights and more than 256 rows (epilogues 0..5 as
-// dlia_gemm_skinny). `workspace` (may be null) of `ws_floats` floats: lets thin shapes split K; its
+// dlia_gemm_skinny). `chunk_max` (may be null; then ldc / n_valid are ignored): see GemmParams. `workspace` (may be null) of `ws_floats` floats: lets thin shapes split K; its
 // last 4096 words are the arrival counters (zero when first handed over, zero after every launch).
 extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const void* bias, const void* residual,
                                 float* workspace, long ws_floats, int M, int N, int K, long ldx, long ldo, long ldr,
-                                int epi, int out_f32, int wg_target, hipStream_t stream) {
+                                int epi, int out_f32, int wg_target, hipStream_t stream, float* chunk_max, long ldc,
+                                int n_valid) {
   if (M <= 0 || N <= 0) return;
   GemmParams p;
+  p.chunk_max = chunk_max; p.ldc = ldc; p.n_valid = n_valid;
   p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = nullptr; p.xscale = nullptr; p.out = out; p.ldo = ldo;
   p.bias = (epi == 1 || epi == 3 || epi == 5) ? (const bf16*)bias : nullptr;
   p.residual = (epi == 2 || epi == 3) ? (const bf16*)residual : nullptr;
@@ -440,7 +467,7 @@ extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const 
   p.ntiles = packed_ntiles(N);
   p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
   p.out_f32 = out_f32; p.partial_only = 0; p.splitk = 1; p.group_n = 1; p.counters = nullptr;
-  if (dlia_gemm_large_choice(-1) != 0) { dlia_gemm_rows(&p, stream); return; }
+  if (dlia_gemm_large_choice(-1) != 0 && chunk_max == nullptr) { dlia_gemm_rows(&p, stream); return; }
   const int s = pp_splitk(M, N, K / 64, wg_target);
   const long tiles = (long)((M + 255) / 256) * ((p.ntiles + 15) / 16);
   if (workspace && s > 1 && ws_floats >= tiles * (s - 1) * kPPSlab + kPPCounters) {

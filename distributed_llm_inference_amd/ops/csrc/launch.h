@@ -58,9 +58,12 @@ void dlia_quant_rows(void* q, float* scale, const void* x, int M, int K, long ld
 int dlia_gemm_rows_set_narrow(int on);
 // bf16 GEMM of more than 256 rows, same epilogues as dlia_gemm_skinny (0..5). workspace / ws_floats (optional):
 // room for the in-launch split-K of thin shapes; its LAST 4096 words are arrival counters, zero between launches.
+// chunk_max (optional, the ping-pong kernel only): per row the maximum of every 32-column chunk of the output
+// (columns >= n_valid excluded), chunk_max[m * ldc + n / 32].
 void dlia_gemm_large(void* out, const void* x, const void* wp, const void* bias, const void* residual,
                      float* workspace, long ws_floats, int M, int N, int K, long ldx, long ldo, long ldr,
-                     int epi, int out_f32, int wg_target, hipStream_t stream);
+                     int epi, int out_f32, int wg_target, hipStream_t stream, float* chunk_max = nullptr, long ldc = 0,
+                     int n_valid = 0);
 extern "C" void dlia_gemm_a8w8_large(void* out, const void* xq, const float* xscale, const void* wp, const float* wscale,
                                      const void* bias, const void* residual, float* workspace, long ws_floats, int M,
                                      int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32, int wg_target,
@@ -86,10 +89,12 @@ long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D
 // ---- sampler.hip ----------------------------------------------------------------------
 // One token per row from fp32 logits [R, ldl] with temperature / top-k / top-p and a
 // counter-based RNG keyed by (seed[r], step[r]); temperature <= 0 -> argmax.
+// chunk_max (optional): per row the maximum of every 32-column chunk of its logits (row stride ldc, at most
+// 4096 chunks), as the lm_head GEMM writes them; the row is then read only where a candidate can be.
 void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
                  const int* top_k, const float* top_p, const uint64_t* seeds,
                  const int* steps, int R, int vocab, long ldl, float* dbg_probs,
-                 int* dbg_ids, int dbg_cap, hipStream_t stream);
+                 int* dbg_ids, int dbg_cap, hipStream_t stream, const float* chunk_max = nullptr, long ldc = 0);
 
 // ---- misc.hip -------------------------------------------------------------------------
 void dlia_advance_i32(int* x, int n, int delta, hipStream_t stream);

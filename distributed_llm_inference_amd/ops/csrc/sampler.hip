@@ -23,6 +23,14 @@
 // one select finds the entry in which the cumulative mass crosses top_p (everything above it, and
 // the ties up to it, is the nucleus), a second one the entry in which it crosses u x kept mass (the
 // draw), and a scan in index order resolves the tie rank. Exact for any k, top_p and tie pattern.
+// With chunk maxima (the lm_head GEMM's epilogue leaves, per row, the maximum of every 32-column chunk):
+// the k-th largest chunk maximum is a lower bound of the k-th largest logit — each of the k chunks
+// at or above it holds at least one value at or above it — so every top-k candidate lies in a chunk
+// whose maximum reaches that bound. The kernel selects that bound exactly (radix select over the <=
+// 4096 maxima in LDS), reads only those chunks (k x 32 values instead of the whole row: 6 KB of a
+// 513 KB row at k = 50, vocabulary 128256) and hands the values at or above the bound to the same
+// sort / cut / draw as before: same candidates or a superset, hence the same token. Greedy rows read
+// one chunk. Tie patterns that overflow the lists fall back to the whole-row methods.
 // Rows must be 16-byte aligned (row stride multiple of 4).
 #include "common.h"
 #include "launch.h"
@@ -31,6 +39,9 @@ namespace dlia {
 
 constexpr int kSampThreads = 1024;
 constexpr int kCap = 1024;            // candidates the sorted path holds in LDS; larger / absent k takes the full-row path
+constexpr int kChunk = 32;            // columns per chunk maximum (gemm_pingpong.hip: one wave's columns of a column half)
+constexpr int kMaxChunks = 4096;      // chunk maxima a row may have (vocabulary <= 131072)
+constexpr int kHotCap = 1024;         // chunks that may reach the bound before the whole-row method takes over
 
 __device__ __forceinline__ unsigned f2key(float f) {
   const unsigned u = __builtin_bit_cast(unsigned, f);
@@ -63,6 +74,7 @@ struct SampleParams {
   const unsigned long long* seeds; const int* steps;
   int vocab;
   float* dbg_probs; int* dbg_ids; int dbg_cap;
+  const float* chunk_max; long ldc; int nchunks;      // optional: maxima of the row's 32-column chunks
 };
 
 
@@ -294,6 +306,51 @@ __device__ void sample_full_row(const SampleParams& p, int r, const float* row, 
   }
 }
 
+// Key of the k-th largest of vals[0, n) (LDS; 1 <= k <= n): four 8-bit radix passes, exact.
+__device__ unsigned lds_kth_key(const float* vals, int n, int k, unsigned* hist, unsigned& s_prefix, unsigned& s_krem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { s_prefix = 0u; s_krem = (unsigned)k; }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = tid; i < n; i += kSampThreads) {
+      const unsigned key = f2key(vals[i]);
+      if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned suf = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+      }
+      const unsigned krem = s_krem;
+      const unsigned above = suf - mine;
+      if (above < krem && krem <= suf) {
+        unsigned cnt = above; int bin;
+        if (cnt + h3 >= krem) bin = 3;
+        else { cnt += h3; if (cnt + h2 >= krem) bin = 2;
+          else { cnt += h2; if (cnt + h1 >= krem) bin = 1; else { cnt += h1; bin = 0; } } }
+        s_prefix = prefix | ((unsigned)(4 * lane + bin) << shift);
+        s_krem = krem - cnt;
+      }
+    }
+    __syncthreads();
+  }
+  return s_prefix;
+}
+
+__device__ __forceinline__ float key2f(unsigned key) {
+  const unsigned u = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+  return __builtin_bit_cast(float, u);
+}
+
 __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   __shared__ unsigned hist[256];
   __shared__ FullShared fsh;
@@ -303,12 +360,53 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   __shared__ float wsum[16];
   __shared__ float s_red[16];
   __shared__ int s_redi[16];
+  __shared__ float cmax[kMaxChunks];
+  __shared__ unsigned short hot[kHotCap];
+  __shared__ unsigned s_nhot;
 
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = p.logits + (long)r * p.ldl;
   const int V = p.vocab;
   const float temp = p.temperature ? p.temperature[r] : 1.f;
+  const int NC = p.chunk_max != nullptr ? p.nchunks : 0;      // > 0: chunk maxima cover the row
+  if (NC > 0) {
+    const float* cm = p.chunk_max + (long)r * p.ldc;
+    for (int c = tid; c < NC; c += kSampThreads) cmax[c] = cm[c];
+    __syncthreads();
+  }
 
+  if (temp <= 0.f && NC > 0) {
+    // greedy from the chunk maxima: the row maximum is the largest of them, its lowest index lies in
+    // the lowest chunk that reaches it
+    float bv = -__builtin_inff();
+    for (int c = tid; c < NC; c += kSampThreads) bv = fmaxf(bv, cmax[c]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bv = fmaxf(bv, __shfl_xor(bv, o, 64));
+    if (lane == 0) s_red[wave] = bv;
+    __syncthreads();
+    for (int w = 0; w < 16; ++w) bv = fmaxf(bv, s_red[w]);
+    int bc = 0x7fffffff;
+    for (int c = tid; c < NC; c += kSampThreads) if (cmax[c] == bv) bc = min(bc, c);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bc = min(bc, __shfl_xor(bc, o, 64));
+    if (lane == 0) s_redi[wave] = bc;
+    __syncthreads();
+    for (int w = 0; w < 16; ++w) bc = min(bc, s_redi[w]);
+    if (wave == 0) {
+      const int col = bc * kChunk + lane;
+      const bool hit = bc != 0x7fffffff && lane < kChunk && col < V && row[col] == bv;
+      const unsigned long long b = __ballot(hit);
+      if (lane == 0) {
+        const int bi = b ? bc * kChunk + (int)__builtin_ctzll(b) : 0;
+        p.out[r] = bi;
+        if (p.dbg_probs) {
+          for (int i = 0; i < p.dbg_cap; ++i) { p.dbg_probs[(long)r * p.dbg_cap + i] = i == 0 ? 1.f : 0.f;
+                                                p.dbg_ids[(long)r * p.dbg_cap + i] = i == 0 ? bi : -1; }
+        }
+      }
+    }
+    return;
+  }
   if (temp <= 0.f) {
     // greedy: max value, lowest index among ties
     float bv = -__builtin_inff(); int bi = 0x7fffffff;
@@ -366,7 +464,36 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
     if (tid == 0) s_ncand = (unsigned)V;
     __syncthreads();
     have = true;
-  } else {
+  } else if (NC > 0 && k <= NC) {
+    // ---- guided by the chunk maxima: only chunks that reach the k-th largest maximum can hold a candidate ----
+    const float bound = key2f(lds_kth_key(cmax, NC, k, hist, s_prefix, s_krem));
+    if (tid == 0) s_nhot = 0u;
+    __syncthreads();
+    for (int c = tid; c < NC; c += kSampThreads)
+      if (cmax[c] >= bound) {
+        const unsigned slot = atomicAdd(&s_nhot, 1u);
+        if (slot < (unsigned)kHotCap) hot[slot] = (unsigned short)c;
+      }
+    __syncthreads();
+    const unsigned nhot = s_nhot;
+    if (nhot <= (unsigned)kHotCap) {
+      for (unsigned h = wave * 2 + (lane >> 5); h < nhot; h += 32) {      // two chunks per wave and turn
+        const int col = (int)hot[h] * kChunk + (lane & 31);
+        if (col < V) {
+          const float v = row[col];
+          if (v >= bound) {
+            const unsigned slot = atomicAdd(&s_ncand, 1u);
+            if (slot < (unsigned)kCap) { cval[slot] = v; cidx[slot] = col; }
+          }
+        }
+      }
+      __syncthreads();
+      const unsigned n = s_ncand;
+      have = n >= (unsigned)k && n <= (unsigned)kCap;
+    }
+    __syncthreads();
+  }
+  if (!have && V > kCap) {
     // Sample: every thread reads one aligned float4 (one cache line per thread: 64 KiB of traffic
     // for 4096 samples) and keeps its maximum. For the small ranks used below, the r-th largest of
     // those 1024 maxima is the r-th largest of all 4096 samples unless two of the top r share a
@@ -568,9 +695,12 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
 extern "C" void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
                             const int* top_k, const float* top_p, const uint64_t* seeds,
                             const int* steps, int R, int vocab, long ldl, float* dbg_probs,
-                            int* dbg_ids, int dbg_cap, hipStream_t stream) {
+                            int* dbg_ids, int dbg_cap, hipStream_t stream, const float* chunk_max, long ldc) {
   if (R <= 0) return;
   dlia::SampleParams p;
+  const int nchunks = (vocab + dlia::kChunk - 1) / dlia::kChunk;
+  const bool guided = chunk_max != nullptr && nchunks <= dlia::kMaxChunks && ldc >= nchunks;
+  p.chunk_max = guided ? chunk_max : nullptr; p.ldc = ldc; p.nchunks = guided ? nchunks : 0;
   p.out = out_tokens; p.logits = logits; p.ldl = ldl; p.temperature = temperature; p.top_k = top_k;
   p.top_p = top_p; p.seeds = (const unsigned long long*)seeds; p.steps = steps; p.vocab = vocab;
   p.dbg_probs = dbg_probs; p.dbg_ids = dbg_ids; p.dbg_cap = dbg_cap > dlia::kCap ? dlia::kCap : dbg_cap;

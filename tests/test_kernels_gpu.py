@@ -756,6 +756,80 @@ def _sample(K, logits, temp, top_k, top_p, seeds, steps, vocab, cap=128):
     return out.cpu(), probs.cpu(), ids.cpu()
 
 
+@pytest.mark.parametrize("shape", [(300, 1000, 256), (520, 50257, 128), (1024, 128256, 256), (700, 32000, 384)])
+def test_gemm_head_writes_logits_and_chunk_maxima(K, shape):
+    """The large-M lm_head: fp32 logits equal to the plain GEMM's (and to an fp32 torch matmul), plus, per
+    row, the maximum of every 32-column chunk over the real vocabulary — padded columns (zero weights,
+    logit 0) excluded, also when the vocabulary ends inside a chunk or inside a 256-column block. With a
+    split-K workspace too (thin shapes)."""
+    M, V, Kd = shape
+    torch.manual_seed(2)
+    x = bf(torch.randn(M, Kd, device=DEV))
+    w = bf(torch.randn(V, Kd, device=DEV) / math.sqrt(Kd)) - 0.05        # mostly negative logits: a padded 0 would win a chunk
+    w = bf(w)
+    wp = packing.pack_weight(w)
+    n_pad = packing.padded_n(V)
+    want = x.float() @ w.float().t()
+    for ws in (None, torch.zeros(int(K.gemm_ws_floats(M, n_pad, Kd)) + 4096, device=DEV)):
+        logits = torch.full((M, n_pad), 7.0, device=DEV)
+        cm = torch.full((M, (n_pad + 255) // 256 * 8), 9.0, device=DEV)
+        K.gemm_head(logits, cm, x, wp, ws, n_pad, V)
+        plain = torch.zeros(M, n_pad, device=DEV)
+        K.gemm(plain, x, wp, None, None, None, n_pad, 0, 0, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(logits[:, :V], plain[:, :V])
+        assert_close(logits[:, :V], want, 2e-2, 2e-2, "logits")
+        nch = (V + 31) // 32
+        padded = torch.full((M, nch * 32), float("-inf"), device=DEV)
+        padded[:, :V] = logits[:, :V]
+        assert torch.equal(cm[:, :nch], padded.view(M, nch, 32).amax(2)), "chunk maxima"
+
+
+def _chunk_max(logits, V):
+    R = logits.shape[0]
+    nch = (V + 31) // 32
+    padded = torch.full((R, nch * 32), float("-inf"), device=logits.device)
+    padded[:, :V] = logits[:, :V]
+    return padded.view(R, nch, 32).amax(2).contiguous()
+
+
+@pytest.mark.parametrize("V", [32000, 50257, 128256])
+def test_guided_sampler_draws_the_same_tokens_as_the_whole_row_sampler(K, V):
+    """With the chunk maxima the sampler reads only the chunks that can hold a candidate; the tokens must
+    be those of the whole-row method for every rule: k = 1 / 5 / 50 / 1024, greedy, rows of exact ties
+    (at the k-th value too), a constant row (every chunk reaches the bound: falls back), a row whose
+    largest values all sit in ONE chunk, and k <= 0 (no top-k: whole-row path either way)."""
+    torch.manual_seed(11)
+    R = 12
+    ld = (V + 127) // 128 * 128
+    logits = torch.randn(R, ld, device=DEV) * 3
+    logits[:, V:] = 1e9
+    logits[2, :V] = (logits[2, :V] * 2).round() / 2                    # heavy ties
+    logits[3, :V] = 0.25                                              # constant row
+    logits[4, 64:96] += 40.0                                          # the whole top-k in one chunk
+    logits[5, :V] = (logits[5, :V]).round()                            # integer logits: ties at the k-th value
+    logits[6, V - 1] = 50.0                                           # the maximum in the last, partial chunk
+    temps = [0.7, 1.0, 0.7, 0.9, 0.7, 0.7, 0.0, 0.0, 1.2, 0.7, 0.7, 0.5]
+    ks = [50, 50, 50, 50, 20, 50, 50, 50, 1, 1024, 0, 5]
+    ps = [0.9, 0.9, 1.0, 1.0, 0.9, 1.0, 0.9, 0.9, 0.9, 0.95, 0.9, 0.3]
+    seeds, steps = list(range(21, 21 + R)), [3] * R
+    cm = _chunk_max(logits, V)
+    for trial in range(3):
+        steps = [trial] * R
+        want, wp_, wi_ = _sample(K, logits, temps, ks, ps, seeds, steps, V)
+        out = torch.full((R,), -1, device=DEV, dtype=torch.int32)
+        probs = torch.zeros(R, 128, device=DEV)
+        ids = torch.zeros(R, 128, device=DEV, dtype=torch.int32)
+        t = lambda v, dt: torch.tensor(v, device=DEV, dtype=dt)
+        K.sample_guided(out, logits, cm, t(temps, torch.float32), t(ks, torch.int32), t(ps, torch.float32), t(seeds, torch.int64),
+                        t(steps, torch.int32), V, probs, ids)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), want), (trial, out.cpu().tolist(), want.tolist())
+        sorted_rows = [r for r in range(R) if ks[r] > 0 and temps[r] > 0]
+        assert torch.equal(ids.cpu()[sorted_rows], wi_[sorted_rows]) and torch.equal(probs.cpu()[sorted_rows], wp_[sorted_rows])
+    assert want[6] == V - 1 and want[7] == logits[7, :V].argmax().item()
+
+
 @pytest.mark.parametrize("V", [320, 32000, 50257, 128256])
 def test_sampler_matches_reference_filter(K, V):
     torch.manual_seed(3)
