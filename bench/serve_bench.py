@@ -43,12 +43,16 @@ def main():
     ap.add_argument("--trace", default=None, help="EngineConfig.trace_path: Chrome trace of host and GPU spans")
     ap.add_argument("--kv-blocks", type=int, default=None, help="EngineConfig.kv_blocks (default: sized from device memory)")
     ap.add_argument("--inflight", type=int, default=None, help="EngineConfig.max_inflight_steps")
+    ap.add_argument("--mixed-prefill", type=int, default=None, choices=[0, 1],
+                    help="EngineConfig.mixed_prefill: running sequences ride in their micro-batch's prefill steps (default: on)")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="closed loop: spread the first CLIENTS arrivals over this long")
     a = ap.parse_args()
     cfg = EngineConfig(model=a.model, pp_size=a.pp_size, max_batch=a.batch, num_micro_batches=a.micro_batches,
                        max_seq_len=a.max_seq_len or ((a.prompt_max + a.new_tokens + 31) // 32) * 32, prefill_chunk=a.prefill_chunk or EngineConfig().prefill_chunk, isolate=a.isolate, dtype=a.dtype, kv_dtype=a.kv_dtype,
                        device="cpu" if a.cpu else "auto", backend="torch" if a.cpu else "auto",
                        transport="loopback" if a.cpu else a.transport)
+    if a.mixed_prefill is not None:
+        cfg.mixed_prefill = bool(a.mixed_prefill)
     if a.admit_fill is not None:
         cfg.admit_fill_fraction = a.admit_fill
     if a.inflight is not None:

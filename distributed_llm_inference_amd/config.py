@@ -40,6 +40,9 @@ class EngineConfig:
     # tiles (Llama-3-8B gate/up: 1792 tiles = 7.0 rounds; 2048 rows: 3.5): prefill alone 91 k tok/s against
     # 82 k, a 4096-request serving run 363 against 339 requests/s with lower TTFT and TPOT (one MI355X)
     prefill_chunk: int = 4096
+    # A prefill step of a micro-batch also carries one decode token for each of its running sequences
+    # (they ride in the same ragged step instead of standing still while newcomers are prefilled)
+    mixed_prefill: bool = True
     kv_blocks: int = 0                     # KV blocks per stage (0 -> sized from free device memory, see kv_mem_fraction)
     kv_mem_fraction: float = 0.85          # share of the memory left after weights and workspaces that the KV cache takes
     use_graphs: bool = True                # hipGraph-captured decode

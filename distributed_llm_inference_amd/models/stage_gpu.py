@@ -421,10 +421,12 @@ class GpuStage:
         return c
 
     def _layers(self, wk: _Work, T: int, B: int, tok_pos, tok_seq, q_start, ctx, slots, max_q: int, splits: int,
-                alone: bool = False):
+                alone: bool = False, lead_decode: int = 0):
         """Runs this stage's decoder layers on wk.h[:T]. Returns the pending split-K partial
         (splits, bias) of the last down projection that the caller still has to fold into h
-        (decode regime), or None when h is final."""
+        (decode regime), or None when h is final. `lead_decode`: the first that many sequences of a
+        ragged step are single decode tokens riding with prompt chunks; their attention runs on the
+        decode-shaped kernel, the chunks' on the prefill-shaped one."""
         K, s = self.K, self.spec
         h, xn, qkv, attn, act = wk.h[:T], wk.xn[:T], wk.qkv[:T], wk.attn[:T], wk.act[:T]
         Hq, Hkv, D, H, I = s.num_heads, s.num_kv_heads, s.head_dim, s.hidden_size, s.intermediate_size
@@ -432,6 +434,14 @@ class GpuStage:
         llama = s.is_llama
         nmode = 0 if llama else 1
         fp8 = self.wmode == "fp8"
+
+        def attend(li):
+            if 0 < lead_decode < B and max_q > 1:
+                n = lead_decode
+                self._attention(li, attn, qkv, q_start[:n + 1], ctx[:n], slots[:n], partial, 1, splits)
+                self._attention(li, attn, qkv, q_start[n:], ctx[n:], slots[n:], partial, max_q, splits)
+            else:
+                self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
 
         def norm(part, S, pbias, w, b):
             """Pre-GEMM norm. In fp8 mode its output is already the GEMM's e4m3 input (returns None)."""
@@ -454,7 +464,7 @@ class GpuStage:
                     x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
                     self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, tg, 0)
                     self._kvwrite(li, qkv, None, 1, None, tok_pos, tok_seq)
-                    self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
+                    attend(li)
                     self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 2 if llama else 3, tg, 0)
                 if "w_down" not in p:       # MLP block runs on the next stage
                     continue
@@ -481,7 +491,7 @@ class GpuStage:
                     x1 = norm(ws, pend[0], pend[1], p["ln1_w"], p.get("ln1_b"))
                 self._gemm(wk, qkv, x1, p, "w_qkv", None, None, ws, s.qkv_size, 6, sq, nq)
                 self._kvwrite(li, qkv, ws, sq, p.get("b_qkv"), tok_pos, tok_seq)
-                self._attention(li, attn, qkv, q_start, ctx, slots, partial, max_q, splits)
+                attend(li)
                 self._gemm(wk, h, attn, p, "w_o", None, None, ws, H, 6, so, no)
                 pend = (so, p.get("b_o"))
             if "w_down" not in p:           # MLP block runs on the next stage: the O partials are folded by the caller
@@ -580,7 +590,12 @@ class GpuStage:
             wk.h[:T].copy_(x.to(device=dev, dtype=torch.bfloat16), non_blocking=True)
         self._eager_sampling = (batch.step_id, R, up[nxt:nxt + 5]) if (self.plan.has_head and R) else None
         max_q = int(q.max()) if B else 1
-        pend = self._layers(wk, T, B, md_tok_pos, md_tok_seq, md_q_start, md_ctx, md_slots, max_q, 1, alone=True)
+        lead = 0                                   # decode tokens riding in front of prompt chunks (Engine._submit_prefill)
+        if max_q > 1:
+            ones = np.flatnonzero(q != 1)
+            lead = int(ones[0]) if ones.size else 0
+        pend = self._layers(wk, T, B, md_tok_pos, md_tok_seq, md_q_start, md_ctx, md_slots, max_q, 1, alone=True,
+                            lead_decode=lead)
         if not self.plan.has_head:
             self._fold(wk, T, pend)
             return wk.h[:T]

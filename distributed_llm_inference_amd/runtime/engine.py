@@ -201,7 +201,8 @@ class Engine:
         # counters for /metrics
         self.stats = {"requests": 0, "completed": 0, "failed": 0, "tokens_out": 0, "tokens_in": 0,
                       "steps": 0, "prefill_steps": 0, "decode_steps": 0, "recompositions": 0,
-                      "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0, "rejected": 0, "rows_moved": 0}
+                      "preemptions": 0, "kv_blocks_grown": 0, "cancelled": 0, "rejected": 0, "rows_moved": 0,
+                      "rider_tokens": 0}
         self.latencies: Deque[float] = collections.deque(maxlen=4096)     # per-token decode latencies (s)
         self.ttfts: Deque[float] = collections.deque(maxlen=1024)
         self.hist_ttft = Histogram(TTFT_BOUNDS)          # arrival -> first token
@@ -639,9 +640,35 @@ class Engine:
         return self._step_id
 
     def _submit_prefill(self, mb: _MicroBatch, pending: List[Request]):
+        """One ragged step: prompt chunks of the micro-batch's newcomers and — `mixed_prefill` — one
+        decode token for each of its running sequences, so that a recomposition does not leave those
+        standing still for as long as the newcomers' prompts take (the reference has neither: one
+        request at a time, whole sequence per step, orchestration.py:109-111)."""
         budget = self.cfg.prefill_chunk
         d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, token_ids=[])
         rows: List[Optional[Request]] = []
+        riders = [r for r in mb.rows if r is not None and r.state == "running" and self._wants_more(r) and r.output] \
+            if self.cfg.mixed_prefill else []
+        # (nothing of this micro-batch is in flight here, so every rider's last token is known; riders need
+        # room in the step next to a worthwhile chunk, a KV block where they cross a boundary, and at least one
+        # real prompt chunk beside them — a step of single tokens only would be a decode step)
+        if riders and (len(riders) > budget // 2 or all(len(r.context) - r.prefilled == 1 for r in pending)
+                       or not self._grow(mb, d)):
+            riders = []
+        for r in riders:
+            d.slots.append(r.slot); d.q_lens.append(1); d.ctx_lens.append(r.issued_ctx); d.sample.append(1)
+            d.temperature.append(r.params.temperature); d.top_k.append(r.params.top_k); d.top_p.append(r.params.top_p)
+            d.seeds.append(r.seed); d.sample_steps.append(r.issued_samples)
+            d.token_ids.append(r.output[-1])
+            if r.moved:
+                d.table_slots.append(r.slot); d.table_blocks.append(list(r.blocks))
+                r.moved = False
+            r.issued_ctx += 1
+            r.issued_samples += 1
+            rows.append(r)
+        budget -= len(riders)
+        if riders:
+            self.stats["rider_tokens"] += len(riders)
         for r in pending:
             if budget <= 0 or len(d.slots) >= self.cfg.max_batch:
                 break

@@ -554,3 +554,33 @@ def test_a_request_cancelled_right_after_submit_never_runs():
         assert st["cancelled"] == 1 and st["completed"] == 1 and st["kv_blocks_used"] == 0
     finally:
         pipe.close()
+
+
+def test_running_sequences_ride_in_the_prefill_steps_of_their_micro_batch():
+    """More requests than rows, different lengths: whenever a micro-batch takes newcomers in, its
+    running sequences get their next token in the same ragged step as the newcomers' prompt chunks
+    (`mixed_prefill`) instead of waiting for the prefill to end. Same greedy tokens as with the
+    option off (the per-sequence arithmetic does not depend on what else is in the step)."""
+    from distributed_llm_inference_amd.parallel.launcher import LocalPipeline
+    g = torch.Generator().manual_seed(4)
+    ps = [torch.randint(3, 250, (int(torch.randint(4, 60, (1,), generator=g)),), generator=g).tolist() for _ in range(14)]
+    lens = [5 + (7 * i) % 23 for i in range(len(ps))]
+
+    def run(mixed, pp):
+        pipe = LocalPipeline(EngineConfig(model="tiny-llama-test", pp_size=pp, max_batch=4, num_micro_batches=2, max_seq_len=128,
+                                          prefill_chunk=24, backend="torch", device="cpu", transport="loopback", seed=2,
+                                          mixed_prefill=mixed))
+        try:
+            reqs = [pipe.engine.submit(p, SamplingParams(temperature=0.0, max_new_tokens=n, stop_on_eos=False)) for p, n in zip(ps, lens)]
+            outs = [r.wait(120).output for r in reqs]
+            assert pipe.engine.wait_idle(10)
+            return outs, pipe.engine.snapshot()
+        finally:
+            pipe.close()
+
+    plain, s0 = run(False, 1)
+    assert s0["rider_tokens"] == 0 and [len(o) for o in plain] == lens
+    for pp in (1, 2):
+        mixed, s1 = run(True, pp)
+        assert mixed == plain
+        assert s1["rider_tokens"] > 0 and s1["failed"] == 0 and s1["kv_blocks_used"] == 0

@@ -420,7 +420,9 @@ def test_decode_steps_shrink_to_the_rows_in_use(pp, mode):
     few, many = prompts(3, seed=31), prompts(70, seed=32)
     want_few, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64, **mode), few, greedy(20))
     want_many, _ = run(cfg(pp_size=pp, num_micro_batches=2, max_batch=64, **mode), many, greedy(12), timeout=300)
-    c = cfg(pp_size=pp, num_micro_batches=2, max_batch=64, decode_buckets=[4, 16, 200], **mode)
+    # (mixed_prefill off: with it the first arrivals finish their 12 tokens while the later ones are still being
+    # prefilled, and the micro-batches never fill up to the 64-row step this test wants to see)
+    c = cfg(pp_size=pp, num_micro_batches=2, max_batch=64, decode_buckets=[4, 16, 200], mixed_prefill=False, **mode)
     assert c.graph_sizes() == [4, 16, 64]
     pipe = LocalPipeline(c)
     try:
@@ -473,7 +475,8 @@ def test_single_stage_process_serves_replay_steps_natively(tmp_path, monkeypatch
     got, snap = run_isolated(cfg(max_seq_len=256, isolate=True))
     assert got == want and snap["fatal"] is None and snap["failed"] == 0
     st = json.loads(stats.read_text())
-    assert st["native_steps"] > 3 * st["handed_to_python"] > 0, st
+    # (64-token prefill steps for 100-200-token prompts, each also carrying the running rows' tokens)
+    assert st["native_steps"] > 2 * st["handed_to_python"] > 0, st
     monkeypatch.setenv("DLIA_NATIVE_LOOP", "0")                       # and the Python loop still gives the same
     stats.unlink()
     again, _ = run_isolated(cfg(max_seq_len=256, isolate=True))
@@ -506,8 +509,9 @@ def test_stages_behind_stage_0_serve_replay_steps_natively(monkeypatch):
         got, snap, stats = run_pp(pp)
         assert got == want and snap["fatal"] is None and snap["failed"] == 0, pp
         for st in stats:
-            # (64-token prefill chunks of 100-200-token prompts: a third of all descriptors are Python's)
-            assert st is not None and st["native_steps"] > 2 * st["handed_to_python"] > 0, (pp, stats)
+            # (64-token prefill steps of 100-200-token prompts, which also carry the running rows' tokens:
+            # a third of all descriptors are Python's)
+            assert st is not None and st["native_steps"] > 1.5 * st["handed_to_python"] > 0, (pp, stats)
     monkeypatch.setenv("DLIA_NATIVE_LOOP", "0")                       # the Python stage loop over the same hops
     got, snap, stats = run_pp(3)
     assert got == want and snap["fatal"] is None and stats == [None, None]
@@ -549,14 +553,15 @@ def test_stragglers_in_high_rows_are_moved_down_so_that_steps_can_shrink(pp):
     split-K rounding of a different row count), across a block boundary after the move."""
     import time
     short, long_ = prompts(38, seed=51), prompts(2, seed=52)
-    plain = cfg(pp_size=pp, num_micro_batches=1, max_batch=64)
+    # (mixed_prefill off: the test counts on all 40 requests starting to decode together)
+    plain = cfg(pp_size=pp, num_micro_batches=1, max_batch=64, mixed_prefill=False)
     pipe = LocalPipeline(plain)
     try:
         reqs = [pipe.engine.submit(p, greedy(6)) for p in short] + [pipe.engine.submit(p, greedy(90)) for p in long_]
         want = [r.wait(300).output for r in reqs]
     finally:
         pipe.close()
-    pipe = LocalPipeline(cfg(pp_size=pp, num_micro_batches=1, max_batch=64, decode_buckets=[4, 16]))
+    pipe = LocalPipeline(cfg(pp_size=pp, num_micro_batches=1, max_batch=64, decode_buckets=[4, 16], mixed_prefill=False))
     try:
         eng = pipe.engine
         reqs = [eng.submit(p, greedy(6)) for p in short] + [eng.submit(p, greedy(90)) for p in long_]
@@ -704,6 +709,7 @@ def test_a_step_counting_fault_fires_at_its_step_with_the_native_loop_serving(mo
         rec = pipe.board.read(1)
         assert rec["state"] == "error" and "injected fault at step 25" in rec["error"], rec
         rt = pipe.runtimes[1]
+        pipe.threads[0].join(60)                      # the stage thread leaves its loop's statistics on its way out
         assert rt.fault.count == 25
         st = getattr(rt, "native_stats", None)
         assert st is not None and st["native_steps"] >= 15, st
