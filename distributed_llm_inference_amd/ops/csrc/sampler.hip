@@ -615,10 +615,14 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
   __syncthreads();
 
   // ---- bitonic sort, descending by value, ascending index among equals -----------------
-  for (int size = 2; size <= kCap; size <<= 1) {
+  // over the smallest power of two that holds the candidates (the guided gather leaves ~k of them:
+  // a 64-element sort is 21 exchange steps, the full 1024-element one 55)
+  int sort_n = 64;
+  while (sort_n < ncand) sort_n <<= 1;
+  for (int size = 2; size <= sort_n; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const int partner = tid ^ stride;
-      if (partner > tid) {
+      if (partner > tid && partner < sort_n) {
         const float a = cval[tid], b = cval[partner];
         const int ai = cidx[tid], bi = cidx[partner];
         const bool a_first = a > b || (a == b && ai < bi);     // a should precede b in final order
