@@ -16,6 +16,12 @@
 // stage: the sampled ids back to stage 0). The hop is reached through a table of three functions,
 // so the RCCL hop between processes (rccl_edge.cpp) and the in-process hop (local_edge.cpp) both fit.
 //
+// And stage 0 of a multi-stage pipeline (dlia_head_serve): descriptor from the scheduler's ring -> growth ->
+// wait for the micro-batch's fed-back ids (the receive the previous step posted into the graph's token
+// buffer) -> hipGraphLaunch -> descriptor on -> send of the hidden states -> receive of THIS step's ids
+// from the last stage posted behind the graph -> their copy to pinned host memory on a side stream ->
+// result ring. `in` is then the token feedback hop, `out` the hop to stage 1.
+//
 // The reference's counterpart is the Flask request handler around model.forward
 // (Worker1.py:208-245; orchestration.py:109-196).
 #include <hip/hip_runtime_api.h>
@@ -64,6 +70,8 @@ struct Mb {
   void* in_ptr = nullptr; size_t in_bytes = 0;
   const void* out_ptr = nullptr; size_t out_bytes = 0;
   int send_tok = -1;                             // completion of the latest send out of out_ptr
+  int fb_tok = -1;                               // stage 0 of several: arrival of the ids the next step reads (in_ptr)
+  int last_slot = -1;                            //   and the host slot they were last copied to (its event guards in_ptr)
   int32_t* host[kSlots] = {};
   hipEvent_t ev[kSlots] = {};
   int next = 0;
@@ -120,6 +128,7 @@ struct Loop {
   uint64_t native_steps = 0, handed_up = 0;
   EdgeRef ein, eout;                             // stage loop only: the hop in, the hop out
   hipStream_t out_stream = nullptr;              // stream the outgoing hop's transfers run on (null: unknown, no send spans)
+  hipStream_t res_stream = nullptr;              // stage 0 of several: where fed-back ids are waited for and copied to the host
   int64_t handoff_in = -1;                       // > 0: hand the n-th replay step from now up to Python instead of serving it
   Timeline tl;
   char err[256] = {0};
@@ -421,11 +430,16 @@ int dlia_stage_set_mb(void* h, int mb, void* exec, void* stream, void* in_ptr, s
 // Before control goes back to the Python loop: the micro-batch streams wait for the sends this loop
 // issued out of their output buffers, so that whatever runs on them next may overwrite those.
 static int stage_flush(Loop* l) {
-  for (Mb& m : l->mbs)
+  for (Mb& m : l->mbs) {
     if (m.send_tok >= 0 && m.stream != nullptr) {
       if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) return hop_fail(l, "wait for a send", l->eout);
       m.send_tok = -1;
     }
+    if (m.fb_tok >= 0 && m.stream != nullptr) {               // stage 0: the ids the micro-batch's next step reads
+      if (l->ein.wait(l->ein.h, m.fb_tok, m.stream) != 0) return hop_fail(l, "wait for the fed-back ids", l->ein);
+      m.fb_tok = -1;
+    }
+  }
   return 0;
 }
 
@@ -503,6 +517,113 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
   }
 }
 
+// ---- stage 0 of a multi-stage pipeline ---------------------------------------------------------------
+// Hops: dlia_stage_set_edges with `in` = the receiving end of the token feedback hop and `out` = the
+// sending end of the hop to stage 1. Micro-batches: dlia_replay_set_mb (graph, stream, the graph's token
+// buffer, rows) followed by dlia_head_set_out (the graph's hidden-state output).
+int dlia_head_set_out(void* h, int mb, const void* out_ptr, size_t out_bytes) {
+  Loop* l = static_cast<Loop*>(h);
+  if (mb < 0 || mb >= (int)l->mbs.size()) { snprintf(l->err, sizeof(l->err), "micro-batch %d out of range", mb); return -1; }
+  Mb& m = l->mbs[mb];
+  m.out_ptr = out_ptr; m.out_bytes = out_bytes;
+  m.in_ptr = const_cast<int32_t*>(m.tokens); m.in_bytes = (size_t)m.rows * 4;
+  m.send_tok = -1; m.fb_tok = -1; m.last_slot = -1;          // whatever Python left pending is on the stream already
+  return 0;
+}
+
+// Serves the scheduler's descriptor ring on stage 0 of several. Returns like dlia_replay_serve. Before a
+// message goes up to Python every micro-batch stream has been made to wait for the ids and sends this
+// loop left pending on it, so the Python loop needs no handles from here.
+int dlia_head_serve(void* h, void* cin_ring, void* res_ring, void* next_ring, void* msg_out, uint32_t cap, uint32_t* len,
+                    int idle_ms) {
+  Loop* l = static_cast<Loop*>(h);
+  if (hipSetDevice(l->device) != hipSuccess) return -1;
+  if (!l->ein.h || !l->eout.h || !next_ring) { snprintf(l->err, sizeof(l->err), "head loop without hops"); return -1; }
+  if (!l->res_stream) HIPCHK(l, hipStreamCreateWithFlags(&l->res_stream, hipStreamNonBlocking));
+  auto t0 = std::chrono::steady_clock::now();
+  const auto t_enter = t0;
+  int idle_spins = 0, since_check = 0;
+  for (;;) {
+    if (drain(l, res_ring) != 0) return -1;
+    tl_reap(l);
+    if (idle_ms >= 0 && ++since_check >= 64) {
+      since_check = 0;
+      if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_enter).count() >= idle_ms)
+        return stage_flush(l) != 0 ? -1 : 0;
+    }
+    const int n = l->rget(cin_ring, msg_out, cap, 0);
+    if (n == -3) return -2;
+    if (n == -2) { snprintf(l->err, sizeof(l->err), "descriptor larger than the message buffer"); return -1; }
+    if (n < 0) {
+      if (++idle_spins > 64) std::this_thread::sleep_for(std::chrono::microseconds(l->pending.empty() ? 100 : 20));
+      else std::this_thread::yield();
+      if (idle_ms >= 0 && l->pending.empty() &&
+          std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= idle_ms)
+        return stage_flush(l) != 0 ? -1 : 0;
+      continue;
+    }
+    idle_spins = 0;
+    t0 = std::chrono::steady_clock::now();
+    const DescHead* d = static_cast<const DescHead*>(msg_out);
+    bool native = (size_t)n >= sizeof(DescHead) && d->magic == kDescMagic && d->kind == kKindStep &&
+                  (d->flags & kFlagCompact) && (d->flags & kFlagReplay) && d->mb >= 0 && d->mb < (int)l->mbs.size() &&
+                  d->ngrow >= 0 && d->ngrow <= kMaxGrow && (size_t)n >= sizeof(DescHead) + (size_t)d->ngrow * 12;
+    if (native) {
+      const Mb& m = l->mbs[d->mb];
+      native = m.exec != nullptr && m.rows == d->rows && m.in_ptr != nullptr && m.out_ptr != nullptr &&
+               (d->ngrow == 0 || l->table != nullptr);
+    }
+    if (native && l->handoff_in > 0 && --l->handoff_in == 0) { native = false; l->handoff_in = -1; }
+    if (!native) {
+      if (stage_flush(l) != 0) return -1;
+      *len = (uint32_t)n;
+      l->handed_up++;
+      return 1;
+    }
+    Mb& m = l->mbs[d->mb];
+    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live);
+    const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
+    for (int i = 0; i < d->ngrow; ++i) {
+      const int slot = g[i], pos = g[d->ngrow + i], blk = g[2 * d->ngrow + i];
+      if (slot < 0 || slot >= l->table_rows || pos < 0 || pos >= l->max_blocks || blk < 0 || blk >= l->num_blocks) continue;
+      int32_t* src = l->grow_stage + (l->grow_pos++ & 4095);
+      *src = blk;
+      HIPCHK(l, hipMemcpyAsync(l->table + (size_t)slot * l->max_blocks + pos, src, 4, hipMemcpyHostToDevice, m.stream));
+    }
+    tl_stamp(l, rec, 0, m.stream);
+    if (m.fb_tok >= 0) {                                      // the ids this step embeds: fed back by the last stage
+      if (l->ein.wait(l->ein.h, m.fb_tok, m.stream) != 0) return hop_fail(l, "wait for the fed-back ids", l->ein);
+      m.fb_tok = -1;
+    }
+    if (m.send_tok >= 0) {                                    // the graph overwrites the output buffer: after its last send
+      if (l->eout.wait(l->eout.h, m.send_tok, m.stream) != 0) return hop_fail(l, "wait for a send", l->eout);
+      m.send_tok = -1;
+    }
+    tl_stamp(l, rec, 1, m.stream);
+    HIPCHK(l, hipGraphLaunch(m.exec, m.stream));
+    tl_stamp(l, rec, 2, m.stream);
+    if (l->rput(next_ring, msg_out, (uint32_t)n, 5000) != 0) {      // descriptor first: the next stage posts its receive
+      snprintf(l->err, sizeof(l->err), "next stage's descriptor ring: put failed");
+      return -1;
+    }
+    m.send_tok = l->eout.send(l->eout.h, m.out_ptr, m.out_bytes, m.stream);
+    if (m.send_tok < 0) return hop_fail(l, "send", l->eout);
+    if (l->out_stream != nullptr) tl_stamp(l, rec, 3, l->out_stream);
+    // This step's ids come back from the last stage into the token buffer: behind the graph that still
+    // reads it (stream order) and behind the copy that took the previous ids out of it.
+    const int s = m.next; m.next = (m.next + 1) % kSlots;
+    if (hipEventQuery(m.ev[s]) == hipErrorNotReady) HIPCHK(l, hipEventSynchronize(m.ev[s]));
+    const int rtok = l->ein.recv(l->ein.h, m.in_ptr, m.in_bytes, m.stream, m.last_slot >= 0 ? m.ev[m.last_slot] : nullptr);
+    if (rtok < 0 || l->ein.wait(l->ein.h, rtok, l->res_stream) != 0) return hop_fail(l, "receive of the fed-back ids", l->ein);
+    HIPCHK(l, hipMemcpyAsync(m.host[s], m.in_ptr, m.in_bytes, hipMemcpyDeviceToHost, l->res_stream));
+    HIPCHK(l, hipEventRecord(m.ev[s], l->res_stream));
+    l->pending.push_back(Pending{d->step_id, m.rows, m.host[s], m.ev[s]});
+    m.fb_tok = rtok; m.last_slot = s;
+    if (rec) rec->host1_ns = now_ns();
+    l->native_steps++;
+  }
+}
+
 // Blocks until every queued result has left (or `timeout_ms` passed: returns 1).
 int dlia_replay_flush(void* h, void* res_ring, int timeout_ms) {
   Loop* l = static_cast<Loop*>(h);
@@ -529,6 +650,7 @@ void dlia_replay_destroy(void* h) {
   for (hipEvent_t e : l->tl.pool) (void)hipEventDestroy(e);
   for (Anchor& a : l->tl.anchors) if (a.ev) (void)hipEventDestroy(a.ev);
   if (l->tl.astream) (void)hipStreamDestroy(l->tl.astream);
+  if (l->res_stream) (void)hipStreamDestroy(l->res_stream);
   delete l;
 }
 

@@ -261,19 +261,29 @@ class RemoteHead:
 
 
 def _native_replay_for(runtime, cin, res):
-    """The native serving loop, when this stage process is a whole single-stage pipeline on a GPU
-    that runs captured decode graphs over shared-memory rings (DLIA_NATIVE_LOOP=0 turns it off)."""
+    """The native serving loop of this stage-0 process, when it runs captured decode graphs on a GPU
+    over shared-memory rings: the single-stage loop, or — several stages, hops with a native end (RCCL)
+    — the stage-0 loop that also forwards the descriptor, sends the hidden states and receives the
+    fed-back ids. DLIA_NATIVE_LOOP=0 turns both off, DLIA_NATIVE_HEAD_LOOP=0 the multi-stage one."""
     import os
     if os.environ.get("DLIA_NATIVE_LOOP", "1") == "0":
         return None
-    ex = runtime.ex
-    if not (runtime.on_gpu and runtime.links.num_stages == 1 and hasattr(ex, "decode_step") and getattr(ex, "use_graphs", False)
+    ex, L = runtime.ex, runtime.links
+    if not (runtime.on_gpu and hasattr(ex, "decode_step") and getattr(ex, "use_graphs", False)
             and not runtime.debug_top5 and hasattr(cin, "ring") and hasattr(res, "ring")):
         return None
-    from .replay import NativeReplay
     dev = torch.device(runtime.device)
-    nr = NativeReplay(dev.index if dev.index is not None else torch.cuda.current_device(), getattr(ex, "decode_states", 1) + 64,
-                      cin.ring, res.ring)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    if L.num_stages == 1:
+        from .replay import NativeReplay
+        nr = NativeReplay(index, getattr(ex, "decode_states", 1) + 64, cin.ring, res.ring)
+    else:
+        if os.environ.get("DLIA_NATIVE_HEAD_LOOP", "1") == "0":
+            return None
+        if not (hasattr(L.next_ctrl, "ring") and hasattr(L.next_data, "native_ends") and hasattr(L.fb_data, "native_ends")):
+            return None
+        from .replay import NativeHeadLoop
+        nr = NativeHeadLoop(index, getattr(ex, "decode_states", 1) + 64, cin.ring, res.ring, L.next_ctrl.ring, L.fb_data, L.next_data)
     nr.set_table(ex.block_table, ex.num_blocks)
     return nr
 
@@ -301,6 +311,7 @@ def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
         if runtime.tracer is not None:
             nr.feed_tracer(runtime.tracer, runtime.stage)
 
+    several = runtime.links.num_stages > 1
     if board is not None:
         board.set_state(runtime.stage, ST_READY)
     step_id = -1
@@ -308,6 +319,16 @@ def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
         while True:
             due = runtime.fault.next_at()                   # a fault rule counts steps: the step it names runs in Python
             nr.handoff_in(due - runtime.fault.count if due is not None else 0)
+            if several:
+                # what the Python loop left pending on the micro-batch streams becomes a stream dependency:
+                # sends out of the static output buffers, the last eager step, the latest fed-back ids
+                from ..parallel.pipeline import _enter_native
+                _enter_native(runtime)
+                for mb, h in list(head._last_fb.items()):
+                    if h is not None and runtime._decode_streams:
+                        with torch.cuda.stream(runtime._decode_streams[mb % len(runtime._decode_streams)]):
+                            h.wait()
+                head._last_fb.clear()
             rc, msg = nr.serve(int(idle_beat_s * 1000))
             account()
             if rc == -2:
@@ -332,7 +353,10 @@ def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
             if runtime._graph_decode(desc) and not desc.replay:
                 # (re)register the micro-batch's captured step: graph, stream, where its ids land
                 st = ex._mb_state(desc.micro_batch, desc.num_seqs)
-                if st.graph is not None:
+                if st.graph is not None and several:
+                    nr.set_mb(desc.micro_batch, st.graph.raw_cuda_graph_exec(), runtime._stream_of(desc).cuda_stream,
+                              ex.input_buffer(desc.micro_batch, desc.num_seqs), st.hidden_out, desc.num_seqs)
+                elif st.graph is not None:
                     nr.set_mb(desc.micro_batch, st.graph.raw_cuda_graph_exec(), runtime._stream_of(desc).cuda_stream,
                               st.tokens.data_ptr(), desc.num_seqs)
     except BaseException as e:
@@ -353,6 +377,7 @@ def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
             if path:
                 with open(path, "w") as f:
                     json.dump(nr.stats(), f)
+            runtime.native_stats = nr.stats()
             runtime.dump_trace()
             runtime.native_loop = None
             nr.close()

@@ -35,6 +35,8 @@ def _lib():
             "dlia_replay_handoff_in": (None, [vp, C.c_long]),
             "dlia_stage_set_mb": (ci, [vp, ci, vp, vp, vp, C.c_size_t, vp, C.c_size_t, ci]),
             "dlia_stage_serve": (ci, [vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
+            "dlia_head_set_out": (ci, [vp, ci, vp, C.c_size_t]),
+            "dlia_head_serve": (ci, [vp, vp, vp, vp, vp, u32, C.POINTER(u32), ci]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -137,6 +139,33 @@ class NativeReplay(_LoopCommon):
         if self.h:
             self.L.dlia_replay_destroy(self.h)
             self.h = None
+
+
+class NativeHeadLoop(NativeReplay):
+    """The native loop of stage 0 of a multi-stage pipeline: replay descriptors from the scheduler's
+    ring -> wait for the micro-batch's fed-back ids -> hipGraphLaunch -> descriptor on -> send of the
+    hidden states -> receive of the step's ids from the last stage -> pinned host copy -> result ring.
+    `next_ring`: stage 1's descriptor ring; `edge_fb` / `edge_out`: the token feedback hop (receiving
+    end) and the hop to stage 1 (sending end), objects with `native_ends()`."""
+
+    def __init__(self, device_index: int, max_mbs: int, cin, res, next_ring, edge_fb, edge_out):
+        super().__init__(device_index, max_mbs, cin, res)
+        self.next_ring = next_ring
+        ih, _, irecv, _, iwait, ierr = edge_fb.native_ends()
+        oh, osend, _, owait, _, oerr = edge_out.native_ends()
+        out_stream = edge_out.native_send_stream() if hasattr(edge_out, "native_send_stream") else 0
+        self.L.dlia_stage_set_edges(self.h, ih, irecv, iwait, ierr, oh, osend, owait, oerr, C.c_void_p(out_stream))
+        self._keep = (edge_fb, edge_out)
+
+    def set_mb(self, mb: int, graph_exec: int, stream: int, tokens, out, rows: int):
+        """`tokens`: the graph's static token-id input (int32 [rows]); `out`: its hidden-state output."""
+        super().set_mb(mb, graph_exec, stream, tokens.data_ptr(), rows)
+        self._check(self.L.dlia_head_set_out(self.h, mb, C.c_void_p(out.data_ptr()), out.numel() * out.element_size()), "set_out")
+
+    def serve(self, idle_ms: int) -> Tuple[int, Optional[bytes]]:
+        rc = self._check(self.L.dlia_head_serve(self.h, self.cin._h, self.res._h, self.next_ring._h, self._buf, self.cin.slot_bytes,
+                                                C.byref(self._len), idle_ms), "native stage-0 loop")
+        return rc, (self._buf.raw[:self._len.value] if rc == 1 else None)
 
 
 class NativeStageLoop(_LoopCommon):

@@ -519,18 +519,24 @@ def test_stages_behind_stage_0_serve_replay_steps_natively(monkeypatch):
 
 @pytest.mark.parametrize("native_loop", [False, True], ids=["python stage loop", "native stage loop"])
 @pytest.mark.parametrize("pp", [2, 4])
-def test_stage_processes_over_native_rccl_hops_give_the_single_stage_tokens(pp, native_loop, monkeypatch):
+def test_stage_processes_over_native_rccl_hops_give_the_single_stage_tokens(pp, native_loop, monkeypatch, tmp_path):
     """Separate OS processes per stage over the NATIVE RCCL transport — per-hop communicators from
     ids broadcast over gloo, ncclSend / ncclRecv on the hop's own stream behind event fences, token
     feedback hop, warm-up messages — on this one GPU: RCCL tells hosts apart by NCCL_HOSTID, and with a
     different id per rank (DLIA_RCCL_DISTINCT_HOSTS) it accepts ranks that share a device and moves
     their messages over its socket transport. The calls, fences and streams are those of a full
     node; only xGMI is missing. Same greedy tokens as the in-process single-stage engine, with the
-    Python stage loop and with the native one behind stage 0 (DLIA_NATIVE_STAGE_LOOP)."""
+    Python loops and with the native ones: behind stage 0 (DLIA_NATIVE_STAGE_LOOP) and on stage 0 itself
+    (DLIA_NATIVE_HEAD_LOOP: descriptor ring -> fed-back ids -> graph -> descriptor on -> send -> receive
+    of the ids -> result ring without entering Python), which must have served most of the steps."""
+    import json
     from distributed_llm_inference_amd.parallel.launcher import SpawnedPipeline
     monkeypatch.setenv("DLIA_SHARE_GPU", "1")
     monkeypatch.setenv("DLIA_RCCL_DISTINCT_HOSTS", "1")
     monkeypatch.setenv("DLIA_NATIVE_STAGE_LOOP", "1" if native_loop else "0")
+    monkeypatch.setenv("DLIA_NATIVE_HEAD_LOOP", "1" if native_loop else "0")
+    stats_path = tmp_path / "head_stats.json"
+    monkeypatch.setenv("DLIA_NATIVE_LOOP_STATS", str(stats_path))
     ps = [p * 2 for p in prompts(12, seed=9)]
     ref, _ = run(cfg(), ps, greedy(24))
     pipe = SpawnedPipeline(cfg(pp_size=pp, num_micro_batches=pp + 1, transport="rccl"))
@@ -543,6 +549,11 @@ def test_stage_processes_over_native_rccl_hops_give_the_single_stage_tokens(pp, 
     finally:
         pipe.close()
     assert got == ref
+    if native_loop:
+        st = json.load(open(stats_path))
+        assert st["native_steps"] > 20 and st["handed_to_python"] > 0, st    # (short run: prefill chunks and recompositions go up)
+    else:
+        assert not stats_path.exists()
 
 
 @pytest.mark.parametrize("pp", [1, 2])
