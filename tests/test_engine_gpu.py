@@ -557,6 +557,39 @@ def test_stage_processes_over_native_rccl_hops_give_the_single_stage_tokens(pp, 
 
 
 @pytest.mark.parametrize("pp", [1, 2])
+def test_running_sequences_ride_in_their_micro_batchs_prefill_steps_on_the_gpu(pp):
+    """More requests than rows and different lengths, so micro-batches admit newcomers while other rows
+    decode: with `mixed_prefill` those rows get their next token inside the newcomers' ragged prefill
+    step (single-token rows on the decode-shaped attention kernel, chunks on the prefill-shaped one).
+    Every request completes with its full length, riders were used, and the greedy tokens agree with
+    the run without riders up to bf16 noise (a rider's GEMMs run at the ragged step's row count, so a
+    near-tie may flip, after which that sequence diverges)."""
+    g = torch.Generator().manual_seed(4)
+    ps = [torch.randint(3, 300, (int(torch.randint(4, 90, (1,), generator=g)),), generator=g).tolist() for _ in range(20)]
+    lens = [6 + (7 * i) % 23 for i in range(len(ps))]
+
+    def go(mixed):
+        pipe = LocalPipeline(cfg(pp_size=pp, max_batch=4, num_micro_batches=2, prefill_chunk=32, mixed_prefill=mixed))
+        try:
+            reqs = [pipe.engine.submit(p, greedy(n)) for p, n in zip(ps, lens)]
+            outs = [r.wait(300).output for r in reqs]
+            pipe.engine.wait_idle()
+            return outs, pipe.engine.snapshot()
+        finally:
+            pipe.close()
+
+    plain, s0 = go(False)
+    mixed, s1 = go(True)
+    assert s0["rider_tokens"] == 0 and s1["rider_tokens"] > 0
+    for s in (s0, s1):
+        assert s["fatal"] is None and s["failed"] == 0 and s["kv_blocks_used"] == 0
+    assert [len(o) for o in plain] == lens and [len(o) for o in mixed] == lens
+    assert sum(a[0] == b[0] for a, b in zip(plain, mixed)) >= len(ps) - 1
+    same = sum(x == y for a, b in zip(plain, mixed) for x, y in zip(a, b))
+    assert same >= 0.85 * sum(lens), (same, sum(lens))
+
+
+@pytest.mark.parametrize("pp", [1, 2])
 def test_stragglers_in_high_rows_are_moved_down_so_that_steps_can_shrink(pp):
     """Two long requests admitted last sit in rows 38 and 39 of a 64-row micro-batch; once the short ones
     are gone they move to rows 0 and 1 (their block tables re-sent under the new slots, no KV data
