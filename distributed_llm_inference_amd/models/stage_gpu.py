@@ -246,7 +246,7 @@ class GpuStage:
             xs=z(rows, dt=torch.float32) if self.wmode == "fp8" else None,
             head_x=z(B, s.hidden_size) if self.plan.has_head else None,
             logits=z(B, self.vocab_pad, dt=torch.float32) if self.plan.has_head else None,
-            cmax=z(B, (self.vocab_pad + 255) // 256 * 8, dt=torch.float32) if self.plan.has_head and B > self.decode_rows else None)
+            cmax=z(B, (self.vocab_pad + 255) // 256 * 8, dt=torch.float32) if self.plan.has_head else None)
 
     def _pack(self, p: Dict[str, torch.Tensor], name: str, w: torch.Tensor):
         """Packs one GEMM weight into MFMA-fragment order; fp8 mode also stores `<name>_s` scales.
@@ -524,9 +524,11 @@ class GpuStage:
         else:
             K.norm(hx, wk.h[:T], None, wk.ws, pend[0], pend[1], self.final_norm_w, self.final_norm_b,
                    rows_idx[:R], s.norm_eps, nmode)
-        # More than `decode_rows` rows: the tiled GEMM also leaves the maximum of every 32-column chunk of every
-        # row, and the sampler reads the logits only where a top-k candidate can be (a few KB of a 513 KB row).
-        wk.guided = wk.cmax is not None and R > self.decode_rows and s.vocab_size <= 131072 and self._guided_ok
+        # The lm_head GEMM (tile kernel above `decode_rows` rows, weight-streaming kernel up to 128) also leaves the maximum
+        # of every 32-column chunk of every row, and the sampler reads the logits only where a top-k candidate can be
+        # (a few KB of a 513 KB row).
+        wk.guided = (wk.cmax is not None and (R > max(256, self.decode_rows) or R <= min(128, self.decode_rows)) and self.vocab_pad % 4 == 0
+                     and s.vocab_size <= 131072 and self._guided_ok)
         if wk.guided:
             K.gemm_head(wk.logits[:R], wk.cmax[:R], hx, self.lm_head, wk.ws, self.vocab_pad, s.vocab_size)
         else:
@@ -660,19 +662,14 @@ class GpuStage:
         pend = self._layers(wk, B, B, st.ctx, st.slots, self._arange[:B + 1], st.ctx, st.slots, 1, st.splits)
         if self.plan.has_head:
             self._head(wk, self._arange, B, B, pend)
-            if wk.guided:
-                K.sample_guided(st.tokens, wk.logits[:B], wk.cmax[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
-                                self.spec.vocab_size, None, None)
-            else:
-                K.sample(st.tokens, wk.logits[:B], st.temperature, st.top_k, st.top_p, st.seeds, st.steps,
-                         self.spec.vocab_size, None, None)
-            K.advance(st.steps, 1)
-            if self.plan.has_embed:
-                st.ids.copy_(st.tokens)      # single-stage pipeline: the feedback hop is local
+            # the thread that writes a row's token also advances the row's draw counter and context length and — single-stage
+            # pipeline, where the feedback hop is local — puts the token into the next step's input ids
+            K.sample_step(st.tokens, wk.logits[:B], wk.cmax[:B] if wk.guided else None, st.temperature, st.top_k, st.top_p,
+                          st.seeds, st.steps, self.spec.vocab_size, st.ids if self.plan.has_embed else None, st.ctx)
         else:
             self._fold(wk, B, pend)
             st.hidden_out.copy_(wk.h[:B])
-        K.advance(st.ctx, 1)
+            K.advance(st.ctx, 1)
 
     @torch.no_grad()
     def decode_step(self, batch: StepBatch, x: Optional[torch.Tensor] = None) -> torch.Tensor:

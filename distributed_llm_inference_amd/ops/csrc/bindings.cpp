@@ -485,7 +485,8 @@ void paged_attention8(Tensor out, const Tensor& qkv, const Tensor& kv_cache, con
 
 static void sample_impl(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, const Tensor& top_k,
                         const Tensor& top_p, const Tensor& seeds, const Tensor& steps, int64_t vocab,
-                        OptTensor dbg_probs, OptTensor dbg_ids, OptTensor chunk_max) {
+                        OptTensor dbg_probs, OptTensor dbg_ids, OptTensor chunk_max, OptTensor ids_out = c10::nullopt,
+                        bool advance_steps = false, OptTensor ctx_advance = c10::nullopt) {
   check_i32(out_tokens, "out_tokens"); check_dev(logits, "logits");
   DLIA_CHECK(logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1, "logits must be fp32 [R, >=vocab]");
   const int64_t R = logits.size(0);
@@ -513,9 +514,22 @@ static void sample_impl(Tensor out_tokens, const Tensor& logits, const Tensor& t
                chunk_max->size(0) >= R && chunk_max->size(1) >= (vocab + 31) / 32, "chunk_max must be fp32 [R, ceil(vocab / 32)]");
     cm = chunk_max->data_ptr<float>(); ldc = chunk_max->stride(0);
   }
+  int* io = nullptr; int* ca = nullptr;
+  if (ids_out.has_value()) {
+    check_i32(*ids_out, "ids_out");
+    DLIA_CHECK(ids_out->numel() >= R && ids_out->is_contiguous(), "ids_out shape");
+    io = ids_out->data_ptr<int>();
+  }
+  if (ctx_advance.has_value()) {
+    check_i32(*ctx_advance, "ctx");
+    DLIA_CHECK(ctx_advance->numel() == R && ctx_advance->is_contiguous(), "ctx must hold one context length per sampled row");
+    ca = ctx_advance->data_ptr<int>();
+  }
+  if (advance_steps) DLIA_CHECK(steps.numel() == R && steps.is_contiguous(), "steps must hold one counter per sampled row");
   dlia_sample(out_tokens.data_ptr<int>(), logits.data_ptr<float>(), temperature.data_ptr<float>(),
               top_k.data_ptr<int>(), top_p.data_ptr<float>(), reinterpret_cast<const uint64_t*>(seeds.data_ptr<int64_t>()),
-              steps.data_ptr<int>(), (int)R, (int)vocab, logits.stride(0), dp, di, cap, cur_stream(), cm, ldc);
+              steps.data_ptr<int>(), (int)R, (int)vocab, logits.stride(0), dp, di, cap, cur_stream(), cm, ldc, io,
+              advance_steps ? steps.data_ptr<int>() : nullptr, ca);
 }
 
 void sample(Tensor out_tokens, const Tensor& logits, const Tensor& temperature, const Tensor& top_k,
@@ -531,13 +545,22 @@ void sample_guided(Tensor out_tokens, const Tensor& logits, const Tensor& chunk_
   sample_impl(out_tokens, logits, temperature, top_k, top_p, seeds, steps, vocab, dbg_probs, dbg_ids, chunk_max);
 }
 
-// lm_head for more than 256 rows: logits[M, N] (fp32) = x[M, K] @ Wp^T, and chunk_max[M, ceil(N / 32)] = the maximum of
+// The sampler of a captured decode step: the draw of `sample` / `sample_guided` (chunk_max given), and by the thread that
+// writes a row's token also the step's bookkeeping — the token into `ids_out` (the next step's input ids), the row's
+// draw counter in `steps` and its context length in `ctx` advanced by one — instead of three more launches.
+void sample_step(Tensor out_tokens, const Tensor& logits, OptTensor chunk_max, const Tensor& temperature, const Tensor& top_k,
+                 const Tensor& top_p, const Tensor& seeds, Tensor steps, int64_t vocab, OptTensor ids_out, OptTensor ctx) {
+  sample_impl(out_tokens, logits, temperature, top_k, top_p, seeds, steps, vocab, c10::nullopt, c10::nullopt, chunk_max, ids_out,
+              true, ctx);
+}
+
+// lm_head for more than 256 rows (or at most 128: the weight-streaming kernel): logits[M, N] (fp32) = x[M, K] @ Wp^T, and chunk_max[M, ceil(N / 32)] = the maximum of
 // every 32-column chunk of every row over the columns < vocab (the sampler's guide). `workspace` as for gemm.
 void gemm_head(Tensor logits, Tensor chunk_max, const Tensor& x, const Tensor& wp, OptTensor workspace, int64_t N,
                int64_t vocab) {
   check_bf16(x, "x"); check_rows(x, "x"); check_dev(logits, "logits"); check_dev(wp, "wp"); check_dev(chunk_max, "chunk_max");
   const int64_t M = x.size(0), K = x.size(1);
-  DLIA_CHECK(M > 256, "gemm_head is the large-M lm_head (use gemm + sample below 257 rows)");
+  DLIA_CHECK(M > 256 || (M >= 1 && M <= 128), "gemm_head serves 1..128 rows (weight-streaming kernel) and more than 256 (tile kernel)");
   DLIA_CHECK(K % 128 == 0 && N % 4 == 0 && vocab > 0 && vocab <= N, "gemm_head: K % 128, N % 4, 0 < vocab <= N");
   const int64_t n_pad = (N + 127) / 128 * 128;
   DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == n_pad * K * 2, "packed weight size");
@@ -545,10 +568,15 @@ void gemm_head(Tensor logits, Tensor chunk_max, const Tensor& x, const Tensor& w
   DLIA_CHECK(logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1 && logits.size(0) >= M &&
              logits.size(1) >= N && logits.stride(0) % 4 == 0 && reinterpret_cast<uintptr_t>(logits.data_ptr()) % 16 == 0,
              "logits must be fp32 [M, >= N], 16-byte aligned rows");
-  // the kernel stores a maximum for every chunk of every 256-column block it computes
+  // the kernels store a maximum for every chunk of every 256-column (tile kernel) / 128-column block they compute
   const int64_t chunks = (n_pad + 255) / 256 * 8;
   DLIA_CHECK(chunk_max.scalar_type() == at::kFloat && chunk_max.dim() == 2 && chunk_max.stride(1) == 1 &&
              chunk_max.size(0) >= M && chunk_max.size(1) >= chunks, "chunk_max must be fp32 [M, >= ", chunks, "]");
+  if (M <= 128) {
+    dlia_gemm_skinny_head(logits.data_ptr(), x.data_ptr(), wp.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), logits.stride(0),
+                          chunk_max.data_ptr<float>(), chunk_max.stride(0), (int)vocab, cur_stream());
+    return;
+  }
   float* wsp = nullptr; int64_t wsn = 0;
   if (workspace.has_value()) {
     check_f32(*workspace, "workspace");
@@ -601,6 +629,7 @@ TORCH_LIBRARY(dlia, m) {
   m.def("attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) -> int");
   m.def("paged_attention(Tensor(a!) out, Tensor qkv, Tensor kv_cache, Tensor q_start, Tensor ctx_lens, Tensor block_table, Tensor? slots, Tensor? partial, int max_q_len, int Hq, int Hkv, int D, float scale, int splits) -> ()");
   m.def("sample(Tensor(a!) out_tokens, Tensor logits, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
+  m.def("sample_step(Tensor(a!) out_tokens, Tensor logits, Tensor? chunk_max, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor(b!) steps, int vocab, Tensor(c!)? ids_out, Tensor(d!)? ctx) -> ()");
   m.def("sample_guided(Tensor(a!) out_tokens, Tensor logits, Tensor chunk_max, Tensor temperature, Tensor top_k, Tensor top_p, Tensor seeds, Tensor steps, int vocab, Tensor? dbg_probs, Tensor? dbg_ids) -> ()");
   m.def("gemm_head(Tensor(a!) logits, Tensor(b!) chunk_max, Tensor x, Tensor wp, Tensor? workspace, int N, int vocab) -> ()");
   m.def("advance(Tensor(a!) x, int delta) -> ()");
@@ -622,6 +651,7 @@ TORCH_LIBRARY_IMPL(dlia, CUDA, m) {
   m.impl("paged_attention", &paged_attention);
   m.impl("sample", &sample);
   m.impl("sample_guided", &sample_guided);
+  m.impl("sample_step", &sample_step);
   m.impl("gemm_head", &gemm_head);
   m.impl("advance", &advance);
   m.impl("scatter_rows", &scatter_rows);

@@ -457,6 +457,26 @@ __global__ __launch_bounds__(kSkinnyThreads, OCC) void gemm_skinny_kernel(GemmPa
       }
     }
   }
+  // As the lm_head (plain fp32 output, no split): the wave's two n-tiles are one 32-column chunk of the logits
+  // row; its maximum over the columns below n_valid goes to chunk_max[m][chunk] for the guided sampler.
+  if constexpr (NTW == 2) {
+    if (p.chunk_max != nullptr) {
+      const int chunk = tile0 >> 1;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((tile0 + j) * 16 + quad * 4 + r < p.n_valid) mx = fmaxf(mx, acc[i][j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const int m = i * 16 + l15;
+        if (quad == 0 && m < p.M) p.chunk_max[(long)m * p.ldc + chunk] = mx;
+      }
+    }
+  }
 }
 
 // Sum S fp32 partials [S][M][N] and apply the epilogue. One thread per 4 output columns.
@@ -612,4 +632,23 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
   else if (M <= 128) launch_skinny_ntw<8>(p, ntw, stream);
   else               launch_skinny_ntw<16>(p, ntw, stream);
   if (splitk > 1 && !p.partial_only) dlia_splitk_reduce(&p, stream);
+}
+
+// lm_head for at most 128 rows: logits[M, N] (fp32) = x @ Wp^T with no split, and chunk_max[m * ldc + n / 32] = the
+// maximum of every 32-column chunk of every row over the columns below n_valid (the padding columns of the packed
+// weight would otherwise compete with real logits), for every chunk of the packed width (N rounded up to 128).
+extern "C" void dlia_gemm_skinny_head(void* logits, const void* x, const void* wp, int M, int N, int K, long ldx, long ldo,
+                                      float* chunk_max, long ldc, int n_valid, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || M > 128) return;
+  GemmParams p;
+  p.counters = nullptr; p.group_n = 1;
+  p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = nullptr; p.xscale = nullptr; p.out = logits; p.ldo = ldo;
+  p.bias = nullptr; p.residual = nullptr; p.ldr = 0; p.partial = nullptr; p.M = M; p.N = N; p.K = K;
+  p.ntiles = packed_ntiles(N);
+  p.act = 0; p.out_f32 = 1; p.partial_only = 0; p.splitk = 1;
+  p.chunk_max = chunk_max; p.ldc = ldc; p.n_valid = n_valid;
+  if (M <= 16)      launch_skinny_ntw<1>(p, 2, stream);
+  else if (M <= 32) launch_skinny_ntw<2>(p, 2, stream);
+  else if (M <= 64) launch_skinny_ntw<4>(p, 2, stream);
+  else              launch_skinny_ntw<8>(p, 2, stream);
 }

@@ -36,6 +36,8 @@ void dlia_rope_kvwrite(void* qkv, const float* partial, int splits, const void* 
 // epi: 0 none, 1 +bias, 2 +residual, 3 +bias+residual, 4 swiglu (interleaved gate/up tiles,
 // N = 2*N_out), 5 +bias then gelu_tanh, 6 fp32 partials [splitk][M][N] only (summed by the
 // consumer kernel). out_f32: write fp32 instead of bf16.
+void dlia_gemm_skinny_head(void* logits, const void* x, const void* wp, int M, int N, int K, long ldx, long ldo,
+                           float* chunk_max, long ldc, int n_valid, hipStream_t stream);
 void dlia_gemm_skinny(void* out, const void* x, const void* wp, const void* bias,
                       const void* residual, float* workspace, const float* wscale,
                       int M, int N, int K, long ldx, long ldo, long ldr, int epi, int out_f32,
@@ -94,7 +96,8 @@ long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D
 void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
                  const int* top_k, const float* top_p, const uint64_t* seeds,
                  const int* steps, int R, int vocab, long ldl, float* dbg_probs,
-                 int* dbg_ids, int dbg_cap, hipStream_t stream, const float* chunk_max = nullptr, long ldc = 0);
+                 int* dbg_ids, int dbg_cap, hipStream_t stream, const float* chunk_max = nullptr, long ldc = 0,
+                 int* ids_out = nullptr, int* steps_adv = nullptr, int* ctx_adv = nullptr);
 
 // ---- misc.hip -------------------------------------------------------------------------
 void dlia_advance_i32(int* x, int n, int delta, hipStream_t stream);

@@ -75,7 +75,17 @@ struct SampleParams {
   int vocab;
   float* dbg_probs; int* dbg_ids; int dbg_cap;
   const float* chunk_max; long ldc; int nchunks;      // optional: maxima of the row's 32-column chunks
+  // optional tail of a captured decode step, done by the thread that writes the token: the token also goes into the
+  // next step's input ids, and the row's draw counter and context length advance by one
+  int* ids_out; int* steps_adv; int* ctx_adv;
 };
+
+__device__ __forceinline__ void emit_token(const SampleParams& p, int r, int tok) {
+  p.out[r] = tok;
+  if (p.ids_out) p.ids_out[r] = tok;
+  if (p.steps_adv) p.steps_adv[r] += 1;             // (every read of the counter lies before a barrier this thread has passed)
+  if (p.ctx_adv) p.ctx_adv[r] += 1;
+}
 
 
 // ---- exact full-row path (k <= 0 or k > kCap) --------------------------------------------------
@@ -292,7 +302,7 @@ __device__ void sample_full_row(const SampleParams& p, int r, const float* row, 
     int before = 0, total = 0;
     for (int w = 0; w < 16; ++w) { if (w < wave) before += sh.redi[w]; total += sh.redi[w]; }
     const int my = seen + before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (eq && my == trank) { p.out[r] = i; sh.found = 1; }
+    if (eq && my == trank) { emit_token(p, r, i); sh.found = 1; }
     seen += total;
     __syncthreads();
     if (sh.found || seen > trank) break;
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
       const unsigned long long b = __ballot(hit);
       if (lane == 0) {
         const int bi = b ? bc * kChunk + (int)__builtin_ctzll(b) : 0;
-        p.out[r] = bi;
+        emit_token(p, r, bi);
         if (p.dbg_probs) {
           for (int i = 0; i < p.dbg_cap; ++i) { p.dbg_probs[(long)r * p.dbg_cap + i] = i == 0 ? 1.f : 0.f;
                                                 p.dbg_ids[(long)r * p.dbg_cap + i] = i == 0 ? bi : -1; }
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
     if (tid == 0) {
       for (int w = 1; w < 16; ++w)
         if (s_red[w] > bv || (s_red[w] == bv && s_redi[w] < bi)) { bv = s_red[w]; bi = s_redi[w]; }
-      p.out[r] = bi == 0x7fffffff ? 0 : bi;
+      emit_token(p, r, bi == 0x7fffffff ? 0 : bi);
       if (p.dbg_probs) {
         for (int i = 0; i < p.dbg_cap; ++i) { p.dbg_probs[(long)r * p.dbg_cap + i] = i == 0 ? 1.f : 0.f;
                                               p.dbg_ids[(long)r * p.dbg_cap + i] = i == 0 ? bi : -1; }
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
     int pick = 0;
     for (int w = 0; w < 16; ++w) pick += s_redi[w];
     if (pick >= nkeep) pick = nkeep - 1;
-    p.out[r] = cidx[pick];
+    emit_token(p, r, cidx[pick]);
   }
   if (p.dbg_probs && tid < p.dbg_cap) {
     p.dbg_probs[(long)r * p.dbg_cap + tid] = tid < nkeep ? e / kept_total : 0.f;
@@ -699,7 +709,8 @@ __global__ __launch_bounds__(kSampThreads) void sample_kernel(SampleParams p) {
 extern "C" void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
                             const int* top_k, const float* top_p, const uint64_t* seeds,
                             const int* steps, int R, int vocab, long ldl, float* dbg_probs,
-                            int* dbg_ids, int dbg_cap, hipStream_t stream, const float* chunk_max, long ldc) {
+                            int* dbg_ids, int dbg_cap, hipStream_t stream, const float* chunk_max, long ldc,
+                            int* ids_out, int* steps_adv, int* ctx_adv) {
   if (R <= 0) return;
   dlia::SampleParams p;
   const int nchunks = (vocab + dlia::kChunk - 1) / dlia::kChunk;
@@ -708,5 +719,6 @@ extern "C" void dlia_sample(int* out_tokens, const float* logits, const float* t
   p.out = out_tokens; p.logits = logits; p.ldl = ldl; p.temperature = temperature; p.top_k = top_k;
   p.top_p = top_p; p.seeds = (const unsigned long long*)seeds; p.steps = steps; p.vocab = vocab;
   p.dbg_probs = dbg_probs; p.dbg_ids = dbg_ids; p.dbg_cap = dbg_cap > dlia::kCap ? dlia::kCap : dbg_cap;
+  p.ids_out = ids_out; p.steps_adv = steps_adv; p.ctx_adv = ctx_adv;
   hipLaunchKernelGGL(dlia::sample_kernel, dim3(R), dim3(dlia::kSampThreads), 0, stream, p);
 }

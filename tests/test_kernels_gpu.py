@@ -756,9 +756,11 @@ def _sample(K, logits, temp, top_k, top_p, seeds, steps, vocab, cap=128):
     return out.cpu(), probs.cpu(), ids.cpu()
 
 
-@pytest.mark.parametrize("shape", [(300, 1000, 256), (520, 50257, 128), (1024, 128256, 256), (700, 32000, 384)])
+@pytest.mark.parametrize("shape", [(300, 1000, 256), (520, 50257, 128), (1024, 128256, 256), (700, 32000, 384),
+                                   (1, 128256, 256), (7, 1000, 256), (40, 50257, 128), (128, 32000, 384)])
 def test_gemm_head_writes_logits_and_chunk_maxima(K, shape):
-    """The large-M lm_head: fp32 logits equal to the plain GEMM's (and to an fp32 torch matmul), plus, per
+    """The lm_head above 256 rows (tile kernel) and up to 128 rows (weight-streaming kernel, no split): fp32 logits
+    equal to the plain GEMM's (and to an fp32 torch matmul), plus, per
     row, the maximum of every 32-column chunk over the real vocabulary — padded columns (zero weights,
     logit 0) excluded, also when the vocabulary ends inside a chunk or inside a 256-column block. With a
     split-K workspace too (thin shapes)."""
@@ -775,7 +777,7 @@ def test_gemm_head_writes_logits_and_chunk_maxima(K, shape):
         cm = torch.full((M, (n_pad + 255) // 256 * 8), 9.0, device=DEV)
         K.gemm_head(logits, cm, x, wp, ws, n_pad, V)
         plain = torch.zeros(M, n_pad, device=DEV)
-        K.gemm(plain, x, wp, None, None, None, n_pad, 0, 0, 0)
+        K.gemm(plain, x, wp, None, None, None, n_pad, 0, 1 if M <= 128 else 0, 2 if M <= 128 else 0)
         torch.cuda.synchronize()
         assert torch.equal(logits[:, :V], plain[:, :V])
         assert_close(logits[:, :V], want, 2e-2, 2e-2, "logits")
@@ -865,6 +867,32 @@ def test_sampler_greedy_and_determinism(K):
     assert torch.equal(out, out2), "same (seed, step) must give the same draw"
     alone, _, _ = _sample(K, logits[2:3].contiguous(), [0.7], [50], [0.9], [7], [3], V)
     assert alone[0] == out[2], "a draw must not depend on the row the request occupies"
+
+
+@pytest.mark.parametrize("guided", [False, True])
+def test_sample_step_draws_like_sample_and_does_the_steps_bookkeeping(K, guided):
+    """`sample_step`: same tokens as `sample` / `sample_guided`, and the thread that writes a row's token
+    also copies it into the next step's ids and advances the row's draw counter and context length —
+    over the greedy, top-k and full-row paths."""
+    torch.manual_seed(12)
+    V, R = 32000, 6
+    logits = torch.randn(R, V + 64, device=DEV)
+    t = lambda v, dt: torch.tensor(v, device=DEV, dtype=dt)
+    temps, ks, ps = t([0.0, 0.7, 0.7, 1.2, 0.9, 0.0], torch.float32), t([50, 50, 0, 1000, 5, 1], torch.int32), t([0.9, 0.9, 0.8, 1.0, 0.5, 1.0], torch.float32)
+    seeds, steps0, ctx0 = t([3, 4, 5, 6, 7, 8], torch.int64), t([0, 9, 2, 5, 1, 0], torch.int32), t([10, 0, 31, 32, 500, 7], torch.int32)
+    cm = _chunk_max(logits, V) if guided else None
+    want = torch.full((R,), -1, device=DEV, dtype=torch.int32)
+    if guided:
+        K.sample_guided(want, logits, cm, temps, ks, ps, seeds, steps0, V, None, None)
+    else:
+        K.sample(want, logits, temps, ks, ps, seeds, steps0, V, None, None)
+    out, ids = torch.full((R,), -1, device=DEV, dtype=torch.int32), torch.full((R,), -1, device=DEV, dtype=torch.int32)
+    steps, ctx = steps0.clone(), ctx0.clone()
+    K.sample_step(out, logits, cm, temps, ks, ps, seeds, steps, V, ids, ctx)
+    assert torch.equal(out, want) and torch.equal(ids, want)
+    assert torch.equal(steps, steps0 + 1) and torch.equal(ctx, ctx0 + 1)
+    K.sample_step(out, logits, cm, temps, ks, ps, seeds, steps, V, None, None)       # no ids, no ctx: only the counter moves
+    assert torch.equal(steps, steps0 + 2) and torch.equal(ctx, ctx0 + 1)
 
 
 def test_sampler_distribution(K):
