@@ -100,7 +100,6 @@ struct Anchor { hipEvent_t ev = nullptr; int64_t host_ns = 0; };
 
 struct Timeline {
   bool on = true;
-  hipStream_t astream = nullptr;                 // private stream the anchors are recorded on (always idle)
   Anchor anchors[2]; int cur = 0; int64_t anchored_ns = 0;
   std::vector<hipEvent_t> pool;
   std::deque<StepRec> open;
@@ -140,18 +139,21 @@ int fail(Loop* l, const char* what, hipError_t e) {
 }
 #define HIPCHK(l, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(l, #expr, e_); } while (0)
 
-// A device-clock anchor: an event on an idle private stream, completed at once, stamped with the host
-// clock. Renewed every few minutes so that event-to-event distances stay small numbers (float
-// milliseconds); the previous anchor stays valid for the steps that were opened under it.
-int tl_anchor(Loop* l) {
+// A device-clock anchor: an event stamped with the host clock at its completion. It is recorded on the stream of the
+// step being opened and waited for — NOT on a stream of its own: one more stream in the process made two micro-batch
+// streams share a hardware queue (HIP maps streams onto GPU_MAX_HW_QUEUES queues, 4 by default) and cost 9-13 % of
+// the throughput of 256-row steps, while the timing events themselves cost nothing measurable. The wait is for
+// whatever that stream has queued: nothing at the first step, a few steps when the anchor is renewed (every few
+// minutes, so that event-to-event distances stay small numbers in float milliseconds; the previous anchor stays
+// valid for the steps that were opened under it).
+int tl_anchor(Loop* l, hipStream_t stream) {
   Timeline& t = l->tl;
-  if (!t.astream && hipStreamCreateWithFlags(&t.astream, hipStreamNonBlocking) != hipSuccess) return -1;
   const int64_t n = now_ns();
   if (t.anchors[t.cur].ev && n - t.anchored_ns < 300000000000LL) return 0;
   const int nxt = t.anchors[t.cur].ev ? 1 - t.cur : t.cur;
   Anchor& a = t.anchors[nxt];
   if (!a.ev && hipEventCreate(&a.ev) != hipSuccess) return -1;
-  if (hipEventRecord(a.ev, t.astream) != hipSuccess || hipEventSynchronize(a.ev) != hipSuccess) return -1;
+  if (hipEventRecord(a.ev, stream) != hipSuccess || hipEventSynchronize(a.ev) != hipSuccess) return -1;
   a.host_ns = now_ns();
   t.cur = nxt; t.anchored_ns = a.host_ns;
   return 0;
@@ -165,11 +167,11 @@ hipEvent_t tl_event(Timeline& t) {
 }
 
 // Opens the record of a step about to be issued; null when the timeline is off or too many steps are open.
-StepRec* tl_open(Loop* l, int step_id, int mb, int rows, int live) {
+StepRec* tl_open(Loop* l, int step_id, int mb, int rows, int live, hipStream_t stream) {
   Timeline& t = l->tl;
   t.tokens += (uint64_t)(live > 0 ? live : 0);
   if (!t.on) return nullptr;
-  if ((int)t.open.size() >= kOpenSteps || tl_anchor(l) != 0) { t.dropped++; return nullptr; }
+  if ((int)t.open.size() >= kOpenSteps || tl_anchor(l, stream) != 0) { t.dropped++; return nullptr; }
   t.open.emplace_back();
   StepRec& r = t.open.back();
   r.step_id = step_id; r.mb = mb; r.rows = rows; r.anchor = t.cur; r.host0_ns = now_ns();
@@ -375,7 +377,7 @@ int dlia_replay_serve(void* h, void* cin_ring, void* res_ring, void* msg_out, ui
       return 1;
     }
     Mb& m = l->mbs[d->mb];
-    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live);
+    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live, m.stream);
     // block-table growth: table[slot][pos] = block, checked like the Python path (a bad entry is skipped)
     const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
     for (int i = 0; i < d->ngrow; ++i) {
@@ -485,7 +487,7 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
       return 1;
     }
     Mb& m = l->mbs[d->mb];
-    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live);
+    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live, m.stream);
     const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
     for (int i = 0; i < d->ngrow; ++i) {
       const int slot = g[i], pos = g[d->ngrow + i], blk = g[2 * d->ngrow + i];
@@ -581,7 +583,7 @@ int dlia_head_serve(void* h, void* cin_ring, void* res_ring, void* next_ring, vo
       return 1;
     }
     Mb& m = l->mbs[d->mb];
-    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live);
+    StepRec* rec = tl_open(l, d->step_id, d->mb, d->rows, d->live, m.stream);
     const int32_t* g = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(msg_out) + sizeof(DescHead));
     for (int i = 0; i < d->ngrow; ++i) {
       const int slot = g[i], pos = g[d->ngrow + i], blk = g[2 * d->ngrow + i];
@@ -649,7 +651,6 @@ void dlia_replay_destroy(void* h) {
     for (hipEvent_t e : r.e) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : l->tl.pool) (void)hipEventDestroy(e);
   for (Anchor& a : l->tl.anchors) if (a.ev) (void)hipEventDestroy(a.ev);
-  if (l->tl.astream) (void)hipStreamDestroy(l->tl.astream);
   if (l->res_stream) (void)hipStreamDestroy(l->res_stream);
   delete l;
 }

@@ -81,34 +81,39 @@ class GpuSpans:
         self.device = device
         self._open: Deque[tuple] = collections.deque()
         self._anchor = None                    # (event, host ns)
-        self._astream = None
+        self._pool: List["torch.cuda.Event"] = []
         self.busy_ns = 0
         self._busy_until_us = 0.0
 
     def _anchored(self):
+        """The device-clock anchor: an event stamped with the host clock at its completion, recorded on the CURRENT
+        stream and waited for. Not on a stream of its own: one more stream in the process made two micro-batch
+        streams share a hardware queue (HIP maps streams onto GPU_MAX_HW_QUEUES queues, 4 by default), which cost
+        9-13 % of the throughput of 256-row steps; the timing events themselves cost nothing measurable. Renewed
+        every few minutes (float milliseconds between events), at the price of waiting for what the stream has queued."""
         now = time.perf_counter_ns()
         if self._anchor is None or now - self._anchor[1] > 300e9:
-            if self._astream is None:
-                self._astream = torch.cuda.Stream(device=self.device)
             ev = torch.cuda.Event(enable_timing=True)
-            ev.record(self._astream)           # an idle private stream: completes at once
+            ev.record(torch.cuda.current_stream(self.device))
             ev.synchronize()
             self._anchor = (ev, time.perf_counter_ns())
         return self._anchor
 
-    def stamp(self, stream=None) -> "torch.cuda.Event":
-        ev = torch.cuda.Event(enable_timing=True)      # (not pooled: adjacent spans share their boundary events)
+    def stamp(self, stream=None, pooled: bool = False) -> "torch.cuda.Event":
+        """`pooled`: the event will bound ONE span added with `recycle=True` (adjacent spans of a traced step share
+        their boundary events, those are not pooled)."""
+        ev = self._pool.pop() if pooled and self._pool else torch.cuda.Event(enable_timing=True)
         ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
         return ev
 
-    def add(self, track: str, name: str, e0, e1, args: Optional[dict] = None, busy: bool = False):
-        self._open.append((self._anchored(), track, name, e0, e1, args or {}, busy))
+    def add(self, track: str, name: str, e0, e1, args: Optional[dict] = None, busy: bool = False, recycle: bool = False):
+        self._open.append((self._anchored(), track, name, e0, e1, args or {}, busy, recycle))
 
     def reap(self, tracer=None, wait: bool = False) -> int:
         """Resolves finished spans (all of them with `wait`); returns the GPU-busy ns they added."""
         added = 0
         while self._open:
-            (aev, ans), track, name, e0, e1, args, busy = self._open[0]
+            (aev, ans), track, name, e0, e1, args, busy, recycle = self._open[0]
             if wait:
                 e1.synchronize()
             elif not e1.query():
@@ -123,6 +128,8 @@ class GpuSpans:
                     self._busy_until_us = t1
             if tracer is not None:
                 tracer.span(track, name, int(t0 * 1e3), int(max(t0, t1) * 1e3), args)
+            if recycle and len(self._pool) < 64:
+                self._pool += [e0, e1]
         self.busy_ns += added
         return added
 
@@ -163,7 +170,8 @@ class StageRuntime:
         # micro-batch -> event after its latest eager step: only that micro-batch's decode steps wait for it
         self._eager_done: Dict[int, "torch.cuda.Event"] = {}
         self._eager_barrier = os.environ.get("DLIA_EAGER_BARRIER") == "1"    # A/B: eager steps order against every micro-batch
-        self.spans = GpuSpans(self.device) if self.on_gpu else None
+        # (DLIA_GPU_SPANS=0: no device-side step timing at all — an A/B switch)
+        self.spans = GpuSpans(self.device) if self.on_gpu and os.environ.get("DLIA_GPU_SPANS", "1") != "0" else None
         self._probe_stream = None         # tracing only: observes when a send has left without holding the compute stream up
 
     # ---- helpers ---------------------------------------------------------------------------
@@ -302,7 +310,7 @@ class StageRuntime:
         prev_send = self._send_pending.pop(mb, None)
         if prev_send is not None:
             prev_send.wait()          # the output buffer of this micro-batch is free again
-        e_in = sp.stamp() if sp is not None else None   # input there, output buffer free: compute starts
+        e_in = sp.stamp(pooled=not traced) if sp is not None else None   # input there, output buffer free: compute starts
         if traced:
             sp.add(f"stage{self.stage}.gpu.mb{mb}", "recv-wait", e_free, e_in, span_args)
         if graph:
@@ -318,8 +326,8 @@ class StageRuntime:
 
         e_out = None
         if sp is not None:
-            e_out = sp.stamp()
-            sp.add(f"stage{self.stage}.gpu.mb{mb}", "compute", e_in, e_out, span_args, busy=True)
+            e_out = sp.stamp(pooled=not traced)
+            sp.add(f"stage{self.stage}.gpu.mb{mb}", "compute", e_in, e_out, span_args, busy=True, recycle=not traced)
 
         # ---- output ----------------------------------------------------------------------
         result = None
@@ -488,6 +496,8 @@ def stage_main(runtime: StageRuntime, idle_beat_s: float = 0.5, drain_timeout_s:
     try:
         nl = _native_stage_loop_for(runtime)
         runtime.native_loop = nl
+        if nl is not None and os.environ.get("DLIA_GPU_SPANS", "1") == "0":
+            nl.timeline(False)
         while True:
             if nl is not None:
                 _enter_native(runtime)

@@ -75,7 +75,8 @@ class LocalHead:
         self.spec = runtime.ex.spec
         self.num_stages = runtime.links.num_stages
         self.on_gpu = runtime.on_gpu
-        self._res_stream = torch.cuda.Stream(device=runtime.device) if self.on_gpu else None
+        # (only where it is used: every stream takes a share of the process's hardware queues)
+        self._res_stream = torch.cuda.Stream(device=runtime.device) if self.on_gpu and self.num_stages > 1 else None
         self._last_fb: Dict[int, Handle] = {}        # micro-batch -> arrival of its latest fed-back tokens
         # Token read-back. One stage: the ids go to pinned host memory on the step's own stream, right
         # behind the graph (a side stream for the copy costs more than the copy: work arriving on a
@@ -297,6 +298,9 @@ def _head_main_native(runtime, head, nr, cin, res, idle_beat_s: float) -> int:
     keep = deque(maxlen=256)             # results (pinned buffers, events) referenced by the native queue
     counted = tokens_counted = busy_counted = 0
     runtime.native_loop = nr
+    import os
+    if os.environ.get("DLIA_GPU_SPANS", "1") == "0":                 # A/B switch: no device-side step timing
+        nr.timeline(False)
 
     def account():
         nonlocal counted, tokens_counted, busy_counted
