@@ -39,8 +39,16 @@ import time
 # A stage process drives up to six HIP streams (eager, two decode streams, token read-back, and one per
 # hop direction); with HIP's default of 4 hardware queues two of them would share a queue, and a
 # receive waiting for its peer at the head of a shared queue stalls the compute behind it — the
-# pipeline would run one micro-batch at a time. Read by the HIP runtime when it initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# pipeline would run one micro-batch at a time. Read by the HIP runtime when it initialises. A smaller exported
+# value is raised to 8 unless the ranks share one card (DLIA_SHARE_GPU=1: they share its queue slots too) or
+# DLIA_KEEP_HW_QUEUES=1 (distributed_llm_inference_amd/__init__.py::ensure_hw_queues, same rule).
+if os.environ.get("DLIA_KEEP_HW_QUEUES") != "1" and os.environ.get("DLIA_SHARE_GPU") != "1":
+    try:
+        _q = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
+    except ValueError:
+        _q = 0
+    if _q < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
 # RCCL and cross-process device buffers use dmabuf IPC handles; the legacy IPC mode is not supported by the driver here
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 

@@ -14,10 +14,7 @@ import json
 import os
 import sys
 
-# more HIP streams than HIP's default 4 hardware queues per process: see bench.py
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# RCCL and cross-process device buffers use dmabuf IPC handles; the legacy IPC mode is not supported by the driver here
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# (GPU_MAX_HW_QUEUES and HSA_ENABLE_IPC_MODE_LEGACY are settled when the package is imported: __init__.py)
 
 from ..config import EngineConfig
 
