@@ -36,19 +36,9 @@ import os
 import sys
 import time
 
-# A stage process drives up to six HIP streams (eager, two decode streams, token read-back, and one per
-# hop direction); with HIP's default of 4 hardware queues two of them would share a queue, and a
-# receive waiting for its peer at the head of a shared queue stalls the compute behind it — the
-# pipeline would run one micro-batch at a time. Read by the HIP runtime when it initialises. A smaller exported
-# value is raised to 8 unless the ranks share one card (DLIA_SHARE_GPU=1: they share its queue slots too) or
-# DLIA_KEEP_HW_QUEUES=1 (distributed_llm_inference_amd/__init__.py::ensure_hw_queues, same rule).
-if os.environ.get("DLIA_KEEP_HW_QUEUES") != "1" and os.environ.get("DLIA_SHARE_GPU") != "1":
-    try:
-        _q = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
-    except ValueError:
-        _q = 0
-    if _q < 8:
-        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# Hardware queues per process: a rank of a multi-rank run that has its GPU to itself gets at least 8 (its hop streams
+# must not share a queue with its compute streams), everything else keeps what the environment says — the rule and the
+# measurements behind it are in distributed_llm_inference_amd/__init__.py (ensure_hw_queues), applied there on import.
 # RCCL and cross-process device buffers use dmabuf IPC handles; the legacy IPC mode is not supported by the driver here
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 

@@ -424,10 +424,20 @@ class SpawnedPipeline:
             self.cin = ShmControl(f"{self.job}_cin", create=True, slot_bytes=slot)
             self.res = ShmControl(f"{self.job}_res", create=True, slot_bytes=max(1 << 14, 64 + 4 * cfg.max_batch + 2048))
             self.procs = []
-            for r in range(world):
-                p = ctx.Process(target=_stage_entry, args=(cfg.to_dict(), r, world, self.job, port), daemon=True)
-                p.start()
-                self.procs.append(p)
+            # (the children learn from the environment they inherit that they are stages of a pipeline of `world` ranks:
+            # a stage of several that owns its GPU wants more hardware queues than a lone one, see the package's __init__)
+            prev_ranks = os.environ.get("DLIA_PP_RANKS")
+            os.environ["DLIA_PP_RANKS"] = str(world)
+            try:
+                for r in range(world):
+                    p = ctx.Process(target=_stage_entry, args=(cfg.to_dict(), r, world, self.job, port), daemon=True)
+                    p.start()
+                    self.procs.append(p)
+            finally:
+                if prev_ranks is None:
+                    os.environ.pop("DLIA_PP_RANKS", None)
+                else:
+                    os.environ["DLIA_PP_RANKS"] = prev_ranks
             try:
                 self.wait_ready(ready_timeout)
                 break
