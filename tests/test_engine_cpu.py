@@ -556,7 +556,7 @@ def test_a_request_cancelled_right_after_submit_never_runs():
         pipe.close()
 
 
-def test_running_sequences_ride_in_the_prefill_steps_of_their_micro_batch():
+def test_running_sequences_ride_in_the_prefill_steps_of_their_micro_batch(monkeypatch):
     """More requests than rows, different lengths: whenever a micro-batch takes newcomers in, its
     running sequences get their next token in the same ragged step as the newcomers' prompt chunks
     (`mixed_prefill`) instead of waiting for the prefill to end. Same greedy tokens as with the
@@ -584,3 +584,9 @@ def test_running_sequences_ride_in_the_prefill_steps_of_their_micro_batch():
         mixed, s1 = run(True, pp)
         assert mixed == plain
         assert s1["rider_tokens"] > 0 and s1["failed"] == 0 and s1["kv_blocks_used"] == 0
+    # Large micro-batches (here: the threshold lowered below these 4 rows): a round's own newcomers do not ride in
+    # its later chunks, only the sequences that were decoding before it — fewer ridden tokens, same output.
+    from distributed_llm_inference_amd.runtime.engine import Engine
+    monkeypatch.setattr(Engine, "NEWCOMERS_RIDE_UP_TO", 0)
+    old_only, s2 = run(True, 1)
+    assert old_only == plain and 0 < s2["rider_tokens"] < s1["rider_tokens"]

@@ -459,3 +459,28 @@ def test_chat_messages_use_the_reference_template_turn_by_turn():
                                   {"role": "assistant", "content": "b"}, {"role": "user", "content": "c"}], default)
     assert got == "<|system|>\nBe brief.</s>\n<|user|>\na</s>\n<|assistant|>\nb</s>\n<|user|>\nc</s>\n<|assistant|>\n"
     assert build_chat_prompt(tok, [{"role": "user", "content": "x"}, {"role": "user", "content": "y"}], default, mode="none") == "x\ny"
+
+
+def test_hardware_queue_rule(monkeypatch):
+    """`ensure_hw_queues`: a rank of a multi-rank job that owns its GPU gets at least 8 hardware queues; a lone
+    stage, ranks sharing a card, a larger exported value and DLIA_KEEP_HW_QUEUES=1 keep what is exported."""
+    import distributed_llm_inference_amd as pkg
+
+    def after(**env):
+        for k in ("GPU_MAX_HW_QUEUES", "WORLD_SIZE", "DLIA_PP_RANKS", "DLIA_SHARE_GPU", "DLIA_KEEP_HW_QUEUES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pkg.ensure_hw_queues()
+        import os
+        return os.environ.get("GPU_MAX_HW_QUEUES")
+
+    assert after(GPU_MAX_HW_QUEUES="4") == "4"                                   # a lone stage
+    assert after(GPU_MAX_HW_QUEUES="4", WORLD_SIZE="1") == "4"
+    assert after(GPU_MAX_HW_QUEUES="4", WORLD_SIZE="8") == "8"                   # a torchrun / self-launched rank
+    assert after(WORLD_SIZE="2") == "8"                                          # nothing exported
+    assert after(GPU_MAX_HW_QUEUES="4", DLIA_PP_RANKS="4") == "8"                # a spawned stage of several
+    assert after(GPU_MAX_HW_QUEUES="16", WORLD_SIZE="8") == "16"                 # a larger value stays
+    assert after(GPU_MAX_HW_QUEUES="4", WORLD_SIZE="8", DLIA_SHARE_GPU="1") == "4"
+    assert after(GPU_MAX_HW_QUEUES="4", WORLD_SIZE="8", DLIA_KEEP_HW_QUEUES="1") == "4"
+    assert after(GPU_MAX_HW_QUEUES="x", WORLD_SIZE="8") == "8"                   # an unreadable value counts as unset
