@@ -1,4 +1,4 @@
-# End-of-round bench.py lines for the configurations BASELINE.md lists (one GPU).
+# bench.py lines for the usual configurations on one GPU: bf16 / fp8 / e4m3 KV, other batch shapes, the other models.
 set -e
 out=gpurun_out/r3m; mkdir -p $out
 run() {

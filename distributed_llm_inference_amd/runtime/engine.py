@@ -639,7 +639,7 @@ class Engine:
         self._step_id += 1
         return self._step_id
 
-    NEWCOMERS_RIDE_UP_TO = 512      # rows per micro-batch up to which a round's newcomers ride in its later chunks
+    NEWCOMERS_RIDE_UP_TO = 512      # rows per micro-batch up to which the newcomers of one admission ride in its later chunks
 
     def _submit_prefill(self, mb: _MicroBatch, pending: List[Request]):
         """One ragged step: prompt chunks of the micro-batch's newcomers and — `mixed_prefill` — one
@@ -649,8 +649,8 @@ class Engine:
         budget = self.cfg.prefill_chunk
         d = StepBatch(step_id=self._next_step_id(), micro_batch=mb.idx, token_ids=[])
         rows: List[Optional[Request]] = []
-        # Riders: the sequences that were decoding before this round of admissions, and — on micro-batches of up to
-        # NEWCOMERS_RIDE_UP_TO rows — also the round's own newcomers once their prompt is in. A token that rides in
+        # Riders: the sequences that were decoding before this admission, and — on micro-batches of up to
+        # NEWCOMERS_RIDE_UP_TO rows — also the admission's own newcomers once their prompt is in. A token that rides in
         # a 4096-token ragged step costs what a prompt token costs (~11 us on Llama-3-8B); a token of a captured
         # decode step costs the step's time over its rows: 47 us at 256 rows (weight streaming), 15 us at 2048
         # (compute-bound). So on small micro-batches every ridden token is a cheap one (closed loop of 512 clients

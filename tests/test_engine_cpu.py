@@ -584,7 +584,7 @@ def test_running_sequences_ride_in_the_prefill_steps_of_their_micro_batch(monkey
         mixed, s1 = run(True, pp)
         assert mixed == plain
         assert s1["rider_tokens"] > 0 and s1["failed"] == 0 and s1["kv_blocks_used"] == 0
-    # Large micro-batches (here: the threshold lowered below these 4 rows): a round's own newcomers do not ride in
+    # Large micro-batches (here: the threshold lowered below these 4 rows): the newcomers of an admission do not ride in
     # its later chunks, only the sequences that were decoding before it — fewer ridden tokens, same output.
     from distributed_llm_inference_amd.runtime.engine import Engine
     monkeypatch.setattr(Engine, "NEWCOMERS_RIDE_UP_TO", 0)
