@@ -1,5 +1,6 @@
 set -e
 out=gpurun_out/r3one; mkdir -p $out
-timeout -k 10 900 python -u -m pytest tests/test_engine_gpu.py tests/test_bench_gpu.py -x -q --timeout 300 --timeout-method thread > $out/tests.log 2>&1 || { tail -60 $out/tests.log; exit 1; }
+timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $out/tests.log 2>&1 || { tail -60 $out/tests.log; exit 1; }
 tail -3 $out/tests.log
-bash bench/debug/r3_run_inproc_pp.sh
+bash bench/rocprof_capture.sh gpurun_out/r3one/b256 --batch 256 --layers 8 > $out/c1.log 2>&1 || { tail -20 $out/c1.log; exit 1; }
+grep -E "sample_kernel|774144|kernels " gpurun_out/r3one/b256/summary.txt

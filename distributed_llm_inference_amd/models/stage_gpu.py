@@ -524,11 +524,10 @@ class GpuStage:
         else:
             K.norm(hx, wk.h[:T], None, wk.ws, pend[0], pend[1], self.final_norm_w, self.final_norm_b,
                    rows_idx[:R], s.norm_eps, nmode)
-        # The lm_head GEMM (tile kernel above `decode_rows` rows, weight-streaming kernel up to 128) also leaves the maximum
+        # The lm_head GEMM (tile kernel above 256 rows, weight-streaming kernels up to there) also leaves the maximum
         # of every 32-column chunk of every row, and the sampler reads the logits only where a top-k candidate can be
         # (a few KB of a 513 KB row).
-        wk.guided = (wk.cmax is not None and (R > max(256, self.decode_rows) or R <= min(128, self.decode_rows)) and self.vocab_pad % 4 == 0
-                     and s.vocab_size <= 131072 and self._guided_ok)
+        wk.guided = wk.cmax is not None and self.vocab_pad % 4 == 0 and s.vocab_size <= 131072 and self._guided_ok
         if wk.guided:
             K.gemm_head(wk.logits[:R], wk.cmax[:R], hx, self.lm_head, wk.ws, self.vocab_pad, s.vocab_size)
         else:

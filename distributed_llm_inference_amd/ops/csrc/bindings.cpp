@@ -554,13 +554,13 @@ void sample_step(Tensor out_tokens, const Tensor& logits, OptTensor chunk_max, c
               true, ctx);
 }
 
-// lm_head for more than 256 rows (or at most 128: the weight-streaming kernel): logits[M, N] (fp32) = x[M, K] @ Wp^T, and chunk_max[M, ceil(N / 32)] = the maximum of
+// lm_head at any row count (up to 256: the weight-streaming kernels, above: the tile kernel): logits[M, N] (fp32) = x[M, K] @ Wp^T, and chunk_max[M, ceil(N / 32)] = the maximum of
 // every 32-column chunk of every row over the columns < vocab (the sampler's guide). `workspace` as for gemm.
 void gemm_head(Tensor logits, Tensor chunk_max, const Tensor& x, const Tensor& wp, OptTensor workspace, int64_t N,
                int64_t vocab) {
   check_bf16(x, "x"); check_rows(x, "x"); check_dev(logits, "logits"); check_dev(wp, "wp"); check_dev(chunk_max, "chunk_max");
   const int64_t M = x.size(0), K = x.size(1);
-  DLIA_CHECK(M > 256 || (M >= 1 && M <= 128), "gemm_head serves 1..128 rows (weight-streaming kernel) and more than 256 (tile kernel)");
+  DLIA_CHECK(M >= 1, "gemm_head: no rows");
   DLIA_CHECK(K % 128 == 0 && N % 4 == 0 && vocab > 0 && vocab <= N, "gemm_head: K % 128, N % 4, 0 < vocab <= N");
   const int64_t n_pad = (N + 127) / 128 * 128;
   DLIA_CHECK(wp.is_contiguous() && wp.numel() * wp.element_size() == n_pad * K * 2, "packed weight size");
@@ -572,7 +572,7 @@ void gemm_head(Tensor logits, Tensor chunk_max, const Tensor& x, const Tensor& w
   const int64_t chunks = (n_pad + 255) / 256 * 8;
   DLIA_CHECK(chunk_max.scalar_type() == at::kFloat && chunk_max.dim() == 2 && chunk_max.stride(1) == 1 &&
              chunk_max.size(0) >= M && chunk_max.size(1) >= chunks, "chunk_max must be fp32 [M, >= ", chunks, "]");
-  if (M <= 128) {
+  if (M <= 256) {
     dlia_gemm_skinny_head(logits.data_ptr(), x.data_ptr(), wp.data_ptr(), (int)M, (int)N, (int)K, x.stride(0), logits.stride(0),
                           chunk_max.data_ptr<float>(), chunk_max.stride(0), (int)vocab, cur_stream());
     return;

@@ -407,6 +407,26 @@ __global__ __launch_bounds__(kR2Threads, 1) void gemm_rows_kernel(GemmParams p) 
     }
   }
   write_acc_tiles<MTW, 2>(p, acc, tile0, l15, quad, ks, mrow0 + mh * (ROWS / 2));
+  // As the lm_head (plain fp32 output, no split): the wave's two n-tiles are one 32-column chunk of the logits row;
+  // its maximum over the columns below n_valid goes to chunk_max[m][chunk] for the guided sampler.
+  if constexpr (!F8) {
+    if (p.chunk_max != nullptr && p.splitk == 1) {
+      const int chunk = tile0 >> 1;
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((tile0 + j) * 16 + quad * 4 + r < p.n_valid) mx = fmaxf(mx, acc[i][j][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const int m = mrow0 + mh * (ROWS / 2) + i * 16 + l15;
+        if (quad == 0 && m < p.M) p.chunk_max[(long)m * p.ldc + chunk] = mx;
+      }
+    }
+  }
 }
 
 // Column blocks per workgroup-order group (see the kernel). Measured: 4 is worth +2.7 % at 4096 rows

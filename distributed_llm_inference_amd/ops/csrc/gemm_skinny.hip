@@ -634,12 +634,13 @@ extern "C" void dlia_gemm_skinny(void* out, const void* x, const void* wp, const
   if (splitk > 1 && !p.partial_only) dlia_splitk_reduce(&p, stream);
 }
 
-// lm_head for at most 128 rows: logits[M, N] (fp32) = x @ Wp^T with no split, and chunk_max[m * ldc + n / 32] = the
+// lm_head for at most 256 rows (up to 128: this file's kernel; 129..256: gemm_rows.hip): logits[M, N] (fp32) = x @ Wp^T
+// with no split, and chunk_max[m * ldc + n / 32] = the
 // maximum of every 32-column chunk of every row over the columns below n_valid (the padding columns of the packed
 // weight would otherwise compete with real logits), for every chunk of the packed width (N rounded up to 128).
 extern "C" void dlia_gemm_skinny_head(void* logits, const void* x, const void* wp, int M, int N, int K, long ldx, long ldo,
                                       float* chunk_max, long ldc, int n_valid, hipStream_t stream) {
-  if (M <= 0 || N <= 0 || M > 128) return;
+  if (M <= 0 || N <= 0 || M > 256) return;
   GemmParams p;
   p.counters = nullptr; p.group_n = 1;
   p.x = (const bf16*)x; p.ldx = ldx; p.wp = (const u32x4*)wp; p.wscale = nullptr; p.xscale = nullptr; p.out = logits; p.ldo = ldo;
@@ -647,7 +648,8 @@ extern "C" void dlia_gemm_skinny_head(void* logits, const void* x, const void* w
   p.ntiles = packed_ntiles(N);
   p.act = 0; p.out_f32 = 1; p.partial_only = 0; p.splitk = 1;
   p.chunk_max = chunk_max; p.ldc = ldc; p.n_valid = n_valid;
-  if (M <= 16)      launch_skinny_ntw<1>(p, 2, stream);
+  if (M > 128)      dlia_gemm_rows(&p, stream);
+  else if (M <= 16) launch_skinny_ntw<1>(p, 2, stream);
   else if (M <= 32) launch_skinny_ntw<2>(p, 2, stream);
   else if (M <= 64) launch_skinny_ntw<4>(p, 2, stream);
   else              launch_skinny_ntw<8>(p, 2, stream);

@@ -757,9 +757,10 @@ def _sample(K, logits, temp, top_k, top_p, seeds, steps, vocab, cap=128):
 
 
 @pytest.mark.parametrize("shape", [(300, 1000, 256), (520, 50257, 128), (1024, 128256, 256), (700, 32000, 384),
-                                   (1, 128256, 256), (7, 1000, 256), (40, 50257, 128), (128, 32000, 384)])
+                                   (1, 128256, 256), (7, 1000, 256), (40, 50257, 128), (128, 32000, 384),
+                                   (129, 1000, 256), (200, 50257, 128), (256, 128256, 256)])
 def test_gemm_head_writes_logits_and_chunk_maxima(K, shape):
-    """The lm_head above 256 rows (tile kernel) and up to 128 rows (weight-streaming kernel, no split): fp32 logits
+    """The lm_head above 256 rows (tile kernel) and up to 256 rows (weight-streaming kernels, no split): fp32 logits
     equal to the plain GEMM's (and to an fp32 torch matmul), plus, per
     row, the maximum of every 32-column chunk over the real vocabulary — padded columns (zero weights,
     logit 0) excluded, also when the vocabulary ends inside a chunk or inside a 256-column block. With a
@@ -777,7 +778,7 @@ def test_gemm_head_writes_logits_and_chunk_maxima(K, shape):
         cm = torch.full((M, (n_pad + 255) // 256 * 8), 9.0, device=DEV)
         K.gemm_head(logits, cm, x, wp, ws, n_pad, V)
         plain = torch.zeros(M, n_pad, device=DEV)
-        K.gemm(plain, x, wp, None, None, None, n_pad, 0, 1 if M <= 128 else 0, 2 if M <= 128 else 0)
+        K.gemm(plain, x, wp, None, None, None, n_pad, 0, 1 if M <= 256 else 0, 2 if M <= 128 else 0)
         torch.cuda.synchronize()
         assert torch.equal(logits[:, :V], plain[:, :V])
         assert_close(logits[:, :V], want, 2e-2, 2e-2, "logits")
