@@ -100,7 +100,12 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // cluster is 8 x v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) instead of 16 x 16x16x32 —
 // the same 512 matrix-pipe cycles, twice the arithmetic. Lane (r, q) of an x fragment holds
 // k = 32 q .. 32 q + 31 of row r: the 16-byte slots 2 q and 2 q + 1 of its row.
-template <bool F8>
+// CMAX: the lm_head instantiation, whose epilogue also leaves the chunk maxima (GemmParams::chunk_max). It is an
+// instantiation of its own because the extra epilogue code changes how hipcc allocates the whole kernel's registers
+// (220 instead of 256 VGPRs, a different main loop): with it compiled into every GEMM, bench.py's default point lost
+// 1.1 % (60.98 against 60.30 ms per step, four position-balanced runs each) — more than half of what the guided
+// sampler it serves brings.
+template <bool F8, bool CMAX = false>
 __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
           for (int j = 0; j < 2; ++j) acc[hm][hn][i][j] *= xs;
       }
   }
-  if (p.chunk_max != nullptr) {
+  if constexpr (CMAX) {
     // ---- lm_head: maximum of each 32-column chunk of each row ------------------------------------
     // A wave holds, per row half and column half, 64 rows x 32 columns: lane (l15, quad) has row
     // i * 16 + l15 and columns (j * 16 + quad * 4 + reg) of them. Eight values per lane, then a max over
@@ -437,18 +442,21 @@ extern "C" long dlia_gemm_pingpong_ws_floats(int M, int N, int K) {
 // bf16, M > 256 (any M is correct; below that the weight-streaming kernels are faster), K a
 // multiple of 64; `p` fully set up by the caller. p->splitk > 1 needs p->partial = slabs for
 // [tiles][splitk - 1] and p->counters = two zero words per tile (the kernel leaves them zero).
-template <bool F8>
+template <bool F8, bool CMAX = false>
 static void launch_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
   static const bool once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pingpong_kernel<F8>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pingpong_kernel<F8, CMAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kPPLds);
     return true;
   }();
   (void)once;
   const int nb = (p->ntiles + 15) / 16, nb8 = (nb + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
-  hipLaunchKernelGGL(gemm_pingpong_kernel<F8>, dim3(nb8 * mblocks * p->splitk), dim3(kPPThreads), kPPLds, stream, *p);
+  hipLaunchKernelGGL((gemm_pingpong_kernel<F8, CMAX>), dim3(nb8 * mblocks * p->splitk), dim3(kPPThreads), kPPLds, stream, *p);
 }
-extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream) { launch_pingpong<false>(p, stream); }
+extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
+  if (p->chunk_max != nullptr) launch_pingpong<false, true>(p, stream);
+  else                         launch_pingpong<false>(p, stream);
+}
 
 // out[M,N] = epi(x[M,K] @ Wp^T) for bf16 weights and more than 256 rows (epilogues 0..5 as
 // dlia_gemm_skinny). `chunk_max` (may be null; then ldc / n_valid are ignored): see GemmParams. `workspace` (may be null) of `ws_floats` floats: lets thin shapes split K; its
