@@ -1,8 +1,9 @@
 """Architecture description of a decoder-only transformer.
 
 A `ModelSpec` is everything the engine needs to know about a checkpoint's
-architecture: it is parsed from a Hugging Face ``config.json`` (Llama family and
-GPT-2 family) or taken from the built-in table of benchmark models.
+architecture: it is parsed from a Hugging Face ``config.json`` (Llama family —
+Llama, Mistral, Qwen2 — and GPT-2 family) or taken from the built-in table of
+benchmark models.
 
 The reference hard-codes one model name as a module constant and leans on
 ``AutoModelForCausalLM`` for everything else (orchestration.py:20,39-47;
@@ -45,6 +46,20 @@ class ModelSpec:
     tie_embeddings: bool = False
     bos_token_id: Optional[int] = None
     eos_token_id: Optional[int] = None
+    # Llama-family variants: which config.json dialect the spec came from ("llama" | "mistral" | "qwen2"),
+    # biases on the q/k/v projections (Qwen2; Llama with `attention_bias`) and on the output projection
+    # (Llama with `attention_bias`), and the attention window of checkpoints trained with one (Mistral)
+    hf_type: str = "llama"
+    qkv_bias: bool = False
+    o_bias: bool = False
+    sliding_window: Optional[int] = None
+
+    def check_context(self, max_seq_len: int):
+        """Attention here is over the whole context. A checkpoint trained with a sliding window gives
+        the same results only while no sequence is longer than the window."""
+        if self.sliding_window is not None and max_seq_len > self.sliding_window:
+            raise ValueError(f"{self.name}: sliding-window attention (window {self.sliding_window}) is not implemented; "
+                             f"contexts up to the window are exact, max_seq_len={max_seq_len} is beyond it")
 
     # ---- derived quantities -------------------------------------------------
     @property
@@ -74,7 +89,7 @@ class ModelSpec:
     def layer_param_count(self) -> int:
         h, i = self.hidden_size, self.intermediate_size
         if self.is_llama:
-            return h * self.qkv_size + self.q_size * h + 3 * h * i + 2 * h
+            return h * self.qkv_size + self.q_size * h + 3 * h * i + 2 * h + self._attn_bias_count()
         # GPT-2: c_attn, c_proj, c_fc, mlp c_proj, all with biases, two LayerNorms
         return (h * 3 * h + 3 * h) + (h * h + h) + (h * i + i) + (i * h + h) + 4 * h
 
@@ -82,8 +97,11 @@ class ModelSpec:
         """Parameters of a layer's attention block (its norm, QKV and output projections)."""
         h = self.hidden_size
         if self.is_llama:
-            return h * self.qkv_size + self.q_size * h + h
+            return h * self.qkv_size + self.q_size * h + h + self._attn_bias_count()
         return (h * 3 * h + 3 * h) + (h * h + h) + 2 * h
+
+    def _attn_bias_count(self) -> int:
+        return (self.qkv_size if self.qkv_bias else 0) + (self.hidden_size if self.o_bias else 0)
 
     def embed_param_count(self) -> int:
         n = self.vocab_size * self.hidden_size
@@ -154,6 +172,15 @@ class ModelSpec:
                     high_freq_factor=float(rs.get("high_freq_factor", 4.0)),
                     original_max_position_embeddings=int(rs.get("original_max_position_embeddings", 8192)),
                 )
+            if cfg.get("mlp_bias"):
+                raise ValueError("mlp_bias=true is not supported (the fused gate/up epilogue has no bias)")
+            hf_type = mt if mt in ("mistral", "qwen2") else "llama"
+            attn_bias = bool(cfg.get("attention_bias", False))
+            window = cfg.get("sliding_window")
+            if hf_type == "qwen2" and not cfg.get("use_sliding_window", False):
+                window = None
+            if hf_type == "llama":
+                window = None
             return ModelSpec(
                 name=name or cfg.get("_name_or_path", "llama"),
                 family="llama",
@@ -171,6 +198,10 @@ class ModelSpec:
                 tie_embeddings=bool(cfg.get("tie_word_embeddings", False)),
                 bos_token_id=cfg.get("bos_token_id"),
                 eos_token_id=_scalar_eos(cfg.get("eos_token_id")),
+                hf_type=hf_type,
+                qkv_bias=True if hf_type == "qwen2" else attn_bias,       # Qwen2: q/k/v always biased, o never
+                o_bias=False if hf_type == "qwen2" else attn_bias,
+                sliding_window=int(window) if window else None,
             )
         raise ValueError(f"unsupported model_type {mt!r} (architectures={archs})")
 
@@ -210,9 +241,20 @@ class ModelSpec:
             "vocab_size": self.vocab_size, "max_position_embeddings": self.max_position,
             "rms_norm_eps": self.norm_eps, "rope_theta": self.rope_theta,
             "tie_word_embeddings": self.tie_embeddings, "hidden_act": "silu",
-            "attention_bias": False, "mlp_bias": False,
+            "attention_bias": self.qkv_bias, "mlp_bias": False,
             "bos_token_id": self.bos_token_id, "eos_token_id": self.eos_token_id,
         }
+        if self.hf_type == "qwen2":
+            cfg.update({"model_type": "qwen2", "architectures": ["Qwen2ForCausalLM"],
+                        "use_sliding_window": self.sliding_window is not None, "sliding_window": self.sliding_window,
+                        "max_window_layers": 0})
+            del cfg["attention_bias"], cfg["mlp_bias"], cfg["head_dim"]
+        elif self.hf_type == "mistral":
+            cfg.update({"model_type": "mistral", "architectures": ["MistralForCausalLM"],
+                        "sliding_window": self.sliding_window})
+            del cfg["attention_bias"], cfg["mlp_bias"]
+        elif self.qkv_bias != self.o_bias:
+            raise ValueError("a Llama config.json has one `attention_bias` for q/k/v and o alike")
         if self.rope_scaling is not None:
             rs = self.rope_scaling
             cfg["rope_scaling"] = {
@@ -248,8 +290,20 @@ BUILTIN_SPECS: Dict[str, ModelSpec] = {
         name="meta-llama/Meta-Llama-3-70B", family="llama", num_layers=80, hidden_size=8192,
         num_heads=64, num_kv_heads=8, head_dim=128, intermediate_size=28672, vocab_size=128256,
         max_position=8192, norm_eps=1e-5, rope_theta=500000.0, bos_token_id=128000, eos_token_id=128001),
+    # Llama-family variants: Mistral (trained with a 4096-token attention window: exact up to there) and
+    # Qwen2 (biases on the q/k/v projections, tied embeddings at this size)
+    "mistral-7b": ModelSpec(
+        name="mistralai/Mistral-7B-v0.1", family="llama", num_layers=32, hidden_size=4096, num_heads=32,
+        num_kv_heads=8, head_dim=128, intermediate_size=14336, vocab_size=32000, max_position=32768,
+        norm_eps=1e-5, rope_theta=10000.0, bos_token_id=1, eos_token_id=2, hf_type="mistral", sliding_window=4096),
+    "qwen2.5-3b": ModelSpec(
+        name="Qwen/Qwen2.5-3B", family="llama", num_layers=36, hidden_size=2048, num_heads=16, num_kv_heads=2,
+        head_dim=128, intermediate_size=11008, vocab_size=151936, max_position=32768, norm_eps=1e-6,
+        rope_theta=1000000.0, tie_embeddings=True, bos_token_id=151643, eos_token_id=151643,
+        hf_type="qwen2", qkv_bias=True),
 }
 # aliases
+BUILTIN_SPECS["mistral-7b-v0.1"] = BUILTIN_SPECS["mistral-7b"]
 BUILTIN_SPECS["tinyllama"] = BUILTIN_SPECS["tinyllama-1.1b"]
 BUILTIN_SPECS["tinyllama-1.1b-chat-v1.0"] = BUILTIN_SPECS["tinyllama-1.1b"]
 BUILTIN_SPECS["gpt2-small"] = BUILTIN_SPECS["gpt2"]
@@ -267,6 +321,9 @@ def _register_test_models():
     BUILTIN_SPECS["tiny-llama-gpu-test"] = tiny_spec(
         "llama", name="tiny-llama-gpu-test", hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
         intermediate_size=512, vocab_size=320, num_layers=4)
+    BUILTIN_SPECS["tiny-qwen2-gpu-test"] = tiny_spec(
+        "llama", name="tiny-qwen2-gpu-test", hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
+        intermediate_size=512, vocab_size=320, num_layers=4, hf_type="qwen2", qkv_bias=True, tie_embeddings=True)
     BUILTIN_SPECS["tiny-gpt2-gpu-test"] = tiny_spec(
         "gpt2", name="tiny-gpt2-gpu-test", hidden_size=256, num_heads=4, num_kv_heads=4, head_dim=64,
         intermediate_size=1024, vocab_size=333, num_layers=4)

@@ -125,6 +125,10 @@ class GpuStage:
             raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
         if spec.head_dim not in (64, 128):
             raise ValueError("the HIP attention kernels support head_dim 64 and 128")
+        if spec.group_size not in (1, 2, 4, 8, 16):
+            raise ValueError(f"{spec.name}: {spec.num_heads} query heads over {spec.num_kv_heads} kv heads — the HIP attention "
+                             "kernels take a GQA group size that is a power of two up to 16")
+        spec.check_context(max_seq_len)
         if weight_dtype not in ("bf16", "fp8", "fp8w"):
             raise ValueError("weight_dtype must be bf16, fp8 or fp8w")
         if kv_dtype not in ("bf16", "fp8"):
@@ -172,10 +176,9 @@ class GpuStage:
                     self._pack(p, "w_gu", packing.interleave_gate_up(g(l["w_gate"]), g(l["w_up"])))
                 else:
                     self._pack(p, "w_fc", g(l["w_fc"]))
-            if not spec.is_llama:
-                for k in ("ln1_b", "ln2_b", "b_qkv", "b_o", "b_fc", "b_down"):
-                    if k in l:
-                        p[k] = g(l[k])
+            for k in ("ln1_b", "ln2_b", "b_qkv", "b_o", "b_fc", "b_down"):      # GPT-2; q/k/v (and o) of Qwen2 / biased Llama
+                if k in l:
+                    p[k] = g(l[k])
             self.layers.append(p)
             weights.layers[i] = {}                 # drop the logical copy as we go (peak memory)
         self.vocab_pad = packing.padded_n(V)
@@ -462,10 +465,10 @@ class GpuStage:
             for li, p in enumerate(self.layers):
                 if "w_qkv" in p:            # attention block (absent from a first layer whose attention ran upstream)
                     x1 = norm(None, 1, None, p["ln1_w"], p.get("ln1_b"))
-                    self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 0 if llama else 1, tg, 0)
+                    self._gemm(wk, qkv, x1, p, "w_qkv", p.get("b_qkv"), None, lws, s.qkv_size, 1 if "b_qkv" in p else 0, tg, 0)
                     self._kvwrite(li, qkv, None, 1, None, tok_pos, tok_seq)
                     attend(li)
-                    self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 2 if llama else 3, tg, 0)
+                    self._gemm(wk, h, attn, p, "w_o", p.get("b_o"), h, lws, H, 3 if "b_o" in p else 2, tg, 0)
                 if "w_down" not in p:       # MLP block runs on the next stage
                     continue
                 x2 = norm(None, 1, None, p["ln2_w"], p.get("ln2_b"))

@@ -34,7 +34,8 @@ class RefStage:
         self.spec, self.plan = spec, plan
         self.dtype, self.device = dtype, torch.device(device)
         self.w = weights.to(device=self.device, dtype=dtype)
-        self.max_seq_len = max_seq_len or spec.max_position
+        self.max_seq_len = max_seq_len or min(spec.max_position, spec.sliding_window or spec.max_position)
+        spec.check_context(self.max_seq_len)
         if spec.is_llama:
             self.cos, self.sin = build_rope_table(spec, self.max_seq_len, self.device)
         # slot -> per-layer [K, V] tensors of shape [len, Hkv, D]

@@ -125,6 +125,12 @@ def random_stage_weights(spec: ModelSpec, plan: StagePlan, seed: int = 0, device
         if mlp:
             l["ln2_w"] = ones(H) + _randn(p + "ln2_w", (H,), seed, device, dtype, std=0.05)
         if spec.is_llama:
+            # (as large as the projections' outputs, like the q/k/v biases of trained Qwen2 checkpoints: a numerics
+            # test then fails when a path drops or misplaces a bias)
+            if attn and spec.qkv_bias:
+                l["b_qkv"] = _randn(p + "b_qkv", (spec.qkv_size,), seed, device, dtype, std=0.3)
+            if attn and spec.o_bias:
+                l["b_o"] = _randn(p + "b_o", (H,), seed, device, dtype, std=0.3)
             if mlp:
                 l["w_gate"] = _randn(p + "w_gate", (I, H), seed, device, dtype)
                 l["w_up"] = _randn(p + "w_up", (I, H), seed, device, dtype)
@@ -163,6 +169,7 @@ def stage_tensor_names(spec: ModelSpec, plan: StagePlan, available=None) -> List
             p = f"model.layers.{i}."
             if plan.has_attn(i):
                 names += [p + "input_layernorm.weight"] + [p + f"self_attn.{x}_proj.weight" for x in "qkvo"]
+                names += [p + f"self_attn.{x}_proj.bias" for x in ("qkv" if spec.qkv_bias else "") + ("o" if spec.o_bias else "")]
             if plan.has_mlp(i):
                 names += [p + "post_attention_layernorm.weight"] + [p + f"mlp.{x}_proj.weight" for x in ("gate", "up", "down")]
         if plan.has_head:
@@ -209,6 +216,10 @@ def load_stage_weights(model_dir: str, spec: ModelSpec, plan: StagePlan, device=
                                         get(p + "self_attn.k_proj.weight"),
                                         get(p + "self_attn.v_proj.weight")], dim=0),
                     "w_o": get(p + "self_attn.o_proj.weight")})
+                if spec.qkv_bias:
+                    l["b_qkv"] = torch.cat([get(p + f"self_attn.{x}_proj.bias") for x in "qkv"], dim=0)
+                if spec.o_bias:
+                    l["b_o"] = get(p + "self_attn.o_proj.bias")
             if plan.has_mlp(i):
                 l.update({
                     "ln2_w": get(p + "post_attention_layernorm.weight"),
@@ -267,6 +278,11 @@ def export_hf_state_dict(parts: List[StageWeights]) -> Dict[str, torch.Tensor]:
                     sd[p + "self_attn.k_proj.weight"] = k
                     sd[p + "self_attn.v_proj.weight"] = v
                     sd[p + "self_attn.o_proj.weight"] = l["w_o"]
+                    if "b_qkv" in l:
+                        for x, b in zip("qkv", torch.split(l["b_qkv"], [spec.q_size, spec.kv_size, spec.kv_size], dim=0)):
+                            sd[p + f"self_attn.{x}_proj.bias"] = b
+                    if "b_o" in l:
+                        sd[p + "self_attn.o_proj.bias"] = l["b_o"]
                 if "w_down" in l:
                     sd[p + "post_attention_layernorm.weight"] = l["ln2_w"]
                     sd[p + "mlp.gate_proj.weight"] = l["w_gate"]

@@ -21,9 +21,12 @@ def hf_model_from(spec: ModelSpec, seed=0):
     import transformers
     cfg = spec.hf_config()
     if spec.is_llama:
-        c = transformers.LlamaConfig(**{k: v for k, v in cfg.items() if k not in ("model_type", "architectures")})
+        conf, cls = {"llama": (transformers.LlamaConfig, transformers.LlamaForCausalLM),
+                     "mistral": (transformers.MistralConfig, transformers.MistralForCausalLM),
+                     "qwen2": (transformers.Qwen2Config, transformers.Qwen2ForCausalLM)}[spec.hf_type]
+        c = conf(**{k: v for k, v in cfg.items() if k not in ("model_type", "architectures")})
         c._attn_implementation = "eager"
-        model = transformers.LlamaForCausalLM(c)
+        model = cls(c)
     else:
         c = transformers.GPT2Config(**{k: v for k, v in cfg.items() if k not in ("model_type", "architectures")})
         c._attn_implementation = "eager"

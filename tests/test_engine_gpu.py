@@ -157,13 +157,15 @@ def test_http_api_over_the_gpu_pipeline():
         backend.close()
 
 
-def test_checkpoint_directory_on_gpu_matches_transformers(tmp_path):
+@pytest.mark.parametrize("model", [MODEL, "tiny-qwen2-gpu-test"])
+def test_checkpoint_directory_on_gpu_matches_transformers(tmp_path, model):
     """HF-format checkpoint (config.json + sharded safetensors) -> per-stage loading -> HIP stages:
     greedy continuation equals transformers' full-recompute greedy decoding on the same weights
-    (the computation the reference performs), up to bf16 near-ties."""
+    (the computation the reference performs), up to bf16 near-ties. Llama, and the Qwen2 dialect (its
+    own config.json keys, biases on q/k/v, tied head) against transformers' Qwen2 model."""
     from helpers import hf_model_from, write_checkpoint
     from distributed_llm_inference_amd.models.spec import ModelSpec
-    spec = ModelSpec.from_pretrained(MODEL)
+    spec = ModelSpec.from_pretrained(model)
     path = write_checkpoint(spec, str(tmp_path / "ckpt"), seed=9, shards=2, dtype=torch.bfloat16)
     ps = prompts(4, seed=8)
     got, _ = run(cfg(model=path, pp_size=2, num_micro_batches=2), ps, greedy(10))

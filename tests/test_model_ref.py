@@ -13,9 +13,19 @@ from distributed_llm_inference_amd.models.weights import random_stage_weights
 from helpers import hf_model_from, step
 
 
-@pytest.mark.parametrize("family", ["llama", "gpt2"])
+VARIANTS = {
+    "llama": lambda: tiny_spec("llama"),
+    "gpt2": lambda: tiny_spec("gpt2"),
+    # Llama-family dialects: q/k/v biases (Qwen2), q/k/v and o biases (Llama with attention_bias), Mistral's config
+    "qwen2": lambda: tiny_spec("llama", name="tiny-qwen2", hf_type="qwen2", qkv_bias=True, tie_embeddings=True),
+    "llama-attention-bias": lambda: tiny_spec("llama", name="tiny-llama-bias", qkv_bias=True, o_bias=True),
+    "mistral": lambda: tiny_spec("llama", name="tiny-mistral", hf_type="mistral", sliding_window=64),
+}
+
+
+@pytest.mark.parametrize("family", sorted(VARIANTS))
 def test_ref_matches_transformers(family):
-    spec = tiny_spec(family)
+    spec = VARIANTS[family]()
     hf = hf_model_from(spec, seed=3)
     plan = make_plans(spec, 1)[0]
     st = RefStage(spec, plan, random_stage_weights(spec, plan, seed=3))
@@ -64,3 +74,22 @@ def test_ref_ragged_batch_equals_single():
     # sample flags select rows
     lc = a.forward(step([0, 1], [1, 1], [9, 4], sample=[0, 1]), torch.tensor([5, 6]))
     assert lc.shape[0] == 1
+
+
+def test_llama_family_dialects_round_trip_through_config_json():
+    """config.json -> spec -> config.json keeps what the engine acts on; a window shorter than the context is refused."""
+    from distributed_llm_inference_amd.models.spec import ModelSpec
+    for name in ("qwen2", "llama-attention-bias", "mistral", "llama"):
+        spec = VARIANTS[name]()
+        back = ModelSpec.from_hf_config(spec.hf_config(), name=spec.name)
+        assert back == spec, name
+    q = ModelSpec.from_hf_config({"model_type": "qwen2", "hidden_size": 128, "num_attention_heads": 4, "num_key_value_heads": 2,
+                                  "num_hidden_layers": 2, "intermediate_size": 256, "vocab_size": 320, "sliding_window": 32,
+                                  "use_sliding_window": False})
+    assert q.qkv_bias and not q.o_bias and q.sliding_window is None
+    m = VARIANTS["mistral"]()
+    plan = make_plans(m, 1)[0]
+    with pytest.raises(ValueError, match="sliding-window"):
+        RefStage(m, plan, random_stage_weights(m, plan, seed=0), max_seq_len=128)
+    with pytest.raises(ValueError, match="mlp_bias"):
+        ModelSpec.from_hf_config({**VARIANTS["llama"]().hf_config(), "mlp_bias": True})

@@ -13,9 +13,12 @@ pytestmark = pytest.mark.gpu
 
 
 def gpu_spec(family):
-    if family == "llama":
+    if family in ("llama", "qwen2", "llama-attention-bias"):
+        # Llama-family dialects: biases on q/k/v (Qwen2), on q/k/v and o (Llama with attention_bias)
+        extra = {"qwen2": dict(hf_type="qwen2", qkv_bias=True, tie_embeddings=True),
+                 "llama-attention-bias": dict(qkv_bias=True, o_bias=True)}.get(family, {})
         return tiny_spec("llama", hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
-                         intermediate_size=512, vocab_size=320, num_layers=3)
+                         intermediate_size=512, vocab_size=320, num_layers=3, **extra)
     return tiny_spec("gpt2", hidden_size=256, num_heads=4, num_kv_heads=4, head_dim=64,
                      intermediate_size=1024, vocab_size=333, num_layers=3)
 
@@ -38,7 +41,7 @@ def close(a, b, what):
     assert err <= 0.05 * scale + 0.02, f"{what}: max err {err:.4f} vs scale {scale:.4f}"
 
 
-@pytest.mark.parametrize("family", ["llama", "gpt2"])
+@pytest.mark.parametrize("family", ["llama", "gpt2", "qwen2", "llama-attention-bias"])
 def test_prefill_and_eager_decode_match_reference(family):
     spec, ref, gpu = build(family, use_graphs=False)
     torch.manual_seed(0)
@@ -63,8 +66,8 @@ def test_prefill_and_eager_decode_match_reference(family):
         ctx = [c + 1 for c in ctx]
 
 
-@pytest.mark.parametrize("kv_dtype", ["bf16", "fp8"])
-@pytest.mark.parametrize("family", ["llama", "gpt2"])
+@pytest.mark.parametrize("family,kv_dtype", [("llama", "bf16"), ("llama", "fp8"), ("gpt2", "bf16"), ("gpt2", "fp8"),
+                                             ("qwen2", "bf16"), ("llama-attention-bias", "fp8")])
 def test_long_prompt_in_chunks_matches_reference_in_one_piece(family, kv_dtype):
     """A 300-token prompt prefilled as chunks of 160 + 140 tokens (each more than 128 query columns per
     sequence, so both run on the prefill-shaped attention kernel, the second one over the cached context
@@ -102,7 +105,7 @@ def test_long_prompt_in_chunks_matches_reference_in_one_piece(family, kv_dtype):
         ctx = [c + 1 for c in ctx]
 
 
-@pytest.mark.parametrize("family", ["llama", "gpt2"])
+@pytest.mark.parametrize("family", ["llama", "gpt2", "qwen2", "llama-attention-bias"])
 def test_graph_decode_matches_reference_greedy(family):
     spec, ref, gpu = build(family, use_graphs=True)
     torch.manual_seed(1)
@@ -206,12 +209,12 @@ def test_stage_boundaries_between_attention_and_mlp_blocks(family, wdtype):
         t3 = tf.clone()                                             # teacher forcing for the fp8 run
 
 
-@pytest.mark.parametrize("mode", ["fp8", "fp8w"])
-def test_fp8_weight_stage_tracks_bf16_stage(mode):
+@pytest.mark.parametrize("mode,family", [("fp8", "llama"), ("fp8w", "llama"), ("fp8", "qwen2"), ("fp8w", "llama-attention-bias")])
+def test_fp8_weight_stage_tracks_bf16_stage(mode, family):
     """fp8 (e4m3 + per-channel scale) layer weights: logits stay close to the bf16-weight stage,
     prefill (sliced streaming GEMMs over > 128 rows), eager decode and graph decode."""
     from distributed_llm_inference_amd.models.stage_gpu import GpuStage
-    spec = gpu_spec("llama")
+    spec = gpu_spec(family)
     plan = make_plans(spec, 1)[0]
     mk = lambda wd: GpuStage(spec, plan, random_stage_weights(spec, plan, seed=5, dtype=torch.bfloat16), max_slots=8,
                              max_seq_len=256, num_blocks=64, max_tokens=320, max_batch=8, weight_dtype=wd)

@@ -204,9 +204,10 @@ def test_partitioner():
 
 
 # ---- checkpoints --------------------------------------------------------------------------------
-@pytest.mark.parametrize("family", ["llama", "gpt2"])
+@pytest.mark.parametrize("family", ["llama", "gpt2", "qwen2", "llama-attention-bias"])
 def test_stage_loader_reads_only_its_tensors(tmp_path, family):
-    spec = tiny_spec(family)
+    spec = {"qwen2": lambda: tiny_spec("llama", hf_type="qwen2", qkv_bias=True, tie_embeddings=True),
+            "llama-attention-bias": lambda: tiny_spec("llama", qkv_bias=True, o_bias=True)}.get(family, lambda: tiny_spec(family))()
     path = write_checkpoint(spec, str(tmp_path / "ckpt"), seed=2, shards=3)
     plans = make_plans(spec, 2, mode="even")
     full = random_stage_weights(spec, make_plans(spec, 1)[0], seed=2)
@@ -222,6 +223,7 @@ def test_stage_loader_reads_only_its_tensors(tmp_path, family):
             for k, v in l.items():
                 assert torch.equal(v, full.layers[li][k]), (li, k)
         assert (w.embed is not None) == (plan.has_embed or (plan.has_head and spec.tie_embeddings))
+        assert all(("b_qkv" in l) == (spec.qkv_bias or spec.is_gpt2) and ("b_o" in l) == (spec.o_bias or spec.is_gpt2) for l in w.layers)
         if plan.has_head:
             assert torch.equal(w.lm_head, full.lm_head) and torch.equal(w.final_norm_w, full.final_norm_w)
         rd.close()
