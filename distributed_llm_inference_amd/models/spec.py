@@ -301,6 +301,16 @@ BUILTIN_SPECS: Dict[str, ModelSpec] = {
         head_dim=128, intermediate_size=11008, vocab_size=151936, max_position=32768, norm_eps=1e-6,
         rope_theta=1000000.0, tie_embeddings=True, bos_token_id=151643, eos_token_id=151643,
         hf_type="qwen2", qkv_bias=True),
+    # GQA groups that are not powers of two: 3 query heads per kv head (Llama-3.2-3B), 7 (Qwen2.5-7B)
+    "llama-3.2-3b": ModelSpec(
+        name="meta-llama/Llama-3.2-3B", family="llama", num_layers=28, hidden_size=3072, num_heads=24, num_kv_heads=8,
+        head_dim=128, intermediate_size=8192, vocab_size=128256, max_position=131072, norm_eps=1e-5,
+        rope_theta=500000.0, rope_scaling=RopeScaling(32.0, 1.0, 4.0, 8192), tie_embeddings=True,
+        bos_token_id=128000, eos_token_id=128001),
+    "qwen2.5-7b": ModelSpec(
+        name="Qwen/Qwen2.5-7B", family="llama", num_layers=28, hidden_size=3584, num_heads=28, num_kv_heads=4,
+        head_dim=128, intermediate_size=18944, vocab_size=152064, max_position=131072, norm_eps=1e-6,
+        rope_theta=1000000.0, bos_token_id=151643, eos_token_id=151643, hf_type="qwen2", qkv_bias=True),
 }
 # aliases
 BUILTIN_SPECS["mistral-7b-v0.1"] = BUILTIN_SPECS["mistral-7b"]

@@ -125,9 +125,9 @@ class GpuStage:
             raise RuntimeError("GpuStage needs a GPU; use RefStage on CPU")
         if spec.head_dim not in (64, 128):
             raise ValueError("the HIP attention kernels support head_dim 64 and 128")
-        if spec.group_size not in (1, 2, 4, 8, 16):
+        if spec.num_heads % spec.num_kv_heads or not 1 <= spec.group_size <= 16:
             raise ValueError(f"{spec.name}: {spec.num_heads} query heads over {spec.num_kv_heads} kv heads — the HIP attention "
-                             "kernels take a GQA group size that is a power of two up to 16")
+                             "kernels take GQA groups of 1 to 16 query heads")
         spec.check_context(max_seq_len)
         if weight_dtype not in ("bf16", "fp8", "fp8w"):
             raise ValueError("weight_dtype must be bf16, fp8 or fp8w")

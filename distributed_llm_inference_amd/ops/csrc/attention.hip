@@ -49,7 +49,8 @@ struct AttnParams {
   const int* slots;               // optional [B]: block_table row of each sequence (else row b)
   int table_rows;
   float* partial;                 // split-KV partials
-  int B, Hq, Hkv, g_shift;        // group size g = 1 << g_shift
+  int B, Hq, Hkv, g_shift;        // query columns per position: 1 << g_shift, the GQA group size rounded up to a power of two
+  int g_real;                     // the group size itself: columns whose head index within the group is >= g_real are padding
   int max_blocks, num_blocks, qtiles, splits;
   float scale_log2;               // softmax scale * log2(e)
   int xcd_map;                    // prefill kernel: 0 plain order, 1 group i on XCD i % 8, r > 1: r XCDs per group (see there)
@@ -95,9 +96,9 @@ __device__ __forceinline__ void paged_attn_body(const AttnParams& p, long item) 
     const int c = nt * 16 + l15;
     const int pl = c >> p.g_shift, hl = c & (g - 1);
     const int qp = qp0 + pl;
-    col_qpos[nt] = (tile_live && qp < q_len) ? qp : -1;
+    col_qpos[nt] = (tile_live && qp < q_len && hl < p.g_real) ? qp : -1;
     col_row[nt] = (long)(t0 + (qp < q_len ? qp : 0));
-    col_head[nt] = kvh * g + hl;
+    col_head[nt] = kvh * p.g_real + hl;
   }
 
   // kv block range of this split; the 4 waves of the workgroup interleave its blocks.
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
   for (int w = threadIdx.x; w < NC * (D / 4); w += 256) {
     const int c = w / (D / 4), d4 = (w - c * (D / 4)) * 4;
     const int qp = qtile * QT + (c >> p.g_shift);
-    if (qp >= q_len) continue;
+    if (qp >= q_len || (c & (g - 1)) >= p.g_real) continue;
     float mt = kNegInf;
     for (int s = 0; s < p.splits; ++s) mt = fmaxf(mt, p.partial[(rec0 + (long)s * NC + c) * (D + 4)]);
     float lt = 0.f;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
       }
     }
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    const int head = kvh * g + (c & (g - 1));
+    const int head = kvh * p.g_real + (c & (g - 1));
     u32x2 v = {pack_bf16(acc[0] * inv, acc[1] * inv), pack_bf16(acc[2] * inv, acc[3] * inv)};
     *reinterpret_cast<u32x2*>(p.out + (long)(t0 + qp) * p.ldo + head * D + d4) = v;
   }
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int qp = qp0 + ((wave * 32 + nt * 16 + l15) >> p.g_shift);
-    col_qpos[nt] = (tile_live && qp < q_len) ? qp : -1;
+    col_qpos[nt] = (tile_live && qp < q_len && ((wave * 32 + nt * 16 + l15) & (g - 1)) < p.g_real) ? qp : -1;
   }
   // wave-uniform: first and last query position of this wave's columns
   const int wq_first = qp0 + ((wave * 32) >> p.g_shift);
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (col_qpos[nt] >= 0)
-        qf[nt][s] = ld16(p.q + (long)(t0 + col_qpos[nt]) * p.ldq + (kvh * g + ((wave * 32 + nt * 16 + l15) & (g - 1))) * D + s * 32 + quad * 8);
+        qf[nt][s] = ld16(p.q + (long)(t0 + col_qpos[nt]) * p.ldq + (kvh * p.g_real + ((wave * 32 + nt * 16 + l15) & (g - 1))) * D + s * 32 + quad * 8);
       else
         qf[nt][s] = u32x4{0, 0, 0, 0};
     }
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnParams p) {
     int le = lane;
     asm volatile("" : "+v"(le));                   // recompute from the lane id instead of keeping the prologue's values live
     const int ce = wave * 32 + nt * 16 + (le & 15);
-    bf16* orow = p.out + (long)(t0 + col_qpos[nt]) * p.ldo + (kvh * g + (ce & (g - 1))) * D + (le >> 4) * 4;
+    bf16* orow = p.out + (long)(t0 + col_qpos[nt]) * p.ldo + (kvh * p.g_real + (ce & (g - 1))) * D + (le >> 4) * 4;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const f32x4 acc = o[dt][nt];
@@ -729,9 +730,17 @@ static inline bool use_prefill_kernel(int max_q_len, int g, int splits) {
   return on && splits <= 1 && g <= 128 && max_q_len * g > 128;
 }
 
+// GQA group size rounded up to a power of two: the number of query columns a position takes in a tile
+// (group sizes 3, 5, 6, 7 ride with padding columns; K/V are still read once per group).
+static inline int padded_group(int Hq, int Hkv) {
+  int g = 1;
+  while (g < Hq / Hkv) g <<= 1;
+  return g;
+}
+
 extern "C" long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D, int splits) {
   if (splits <= 1) return 0;
-  const int g = Hq / Hkv;
+  const int g = padded_group(Hq, Hkv);
   const int nt = attn_nt(max_q_len, g);
   const int qt = (nt * 16) / g;
   const long qtiles = (max_q_len + qt - 1) / qt;
@@ -748,7 +757,8 @@ extern "C" void dlia_paged_attention(void* out, const void* qkv, const void* kv_
   p.out = (bf16*)out; p.ldo = ldo; p.q = (const bf16*)qkv; p.ldq = ldq; p.kv = (const bf16*)kv_cache; p.kv_scale = kv_scale;
   p.q_start = q_start; p.ctx_lens = ctx_lens; p.block_table = block_table; p.slots = slots; p.table_rows = table_rows; p.partial = partial;
   p.B = B; p.Hq = Hq; p.Hkv = Hkv;
-  const int g = Hq / Hkv;
+  p.g_real = Hq / Hkv;
+  const int g = padded_group(Hq, Hkv);
   int gs = 0;
   while ((1 << gs) < g) ++gs;
   p.g_shift = gs;

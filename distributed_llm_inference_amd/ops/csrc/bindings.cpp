@@ -436,7 +436,7 @@ static void paged_attention_impl(Tensor out, const Tensor& qkv, const Tensor& kv
   DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
   DLIA_CHECK(Hq % Hkv == 0, "Hq must be a multiple of Hkv");
   const int64_t g = Hq / Hkv;
-  DLIA_CHECK(g == 1 || g == 2 || g == 4 || g == 8 || g == 16, "GQA group size must be a power of two <= 16");
+  DLIA_CHECK(g >= 1 && g <= 16, "GQA group size must be between 1 and 16");
   DLIA_CHECK(qkv.size(1) >= Hq * D && out.size(1) >= Hq * D, "qkv/out width");
   auto geo = kv_scale.has_value() ? check_kv8(kv_cache, *kv_scale, Hkv, D) : check_kv(kv_cache, Hkv, D);
   check_i32(q_start, "q_start"); check_i32(ctx_lens, "ctx_lens"); check_i32(block_table, "block_table");

@@ -711,6 +711,25 @@ def test_attention_prefill_long_chunks(K, geom, kv8):
     _attn_case(K, Hq, Hkv, D, ctx_lens=[0], q_lens=[600], splits=1, seed=6, kv8=kv8)
 
 
+@pytest.mark.parametrize("kv8", [False, True])
+@pytest.mark.parametrize("geom", [(24, 8, 128), (28, 4, 128), (12, 2, 128), (40, 8, 128), (14, 2, 64)])
+def test_attention_gqa_groups_that_are_not_powers_of_two(K, geom, kv8):
+    """Groups of 3 (Llama-3.2-3B), 7 (Qwen2.5-7B / 0.5B), 6 and 5 query heads per kv head: a position takes the next
+    power of two of query columns and the surplus columns are padding. Every kernel shape: decode with four waves per
+    item, with one wave per item (>= 1024 items), split KV with the combine kernel, ragged chunks (two column tiles per
+    workgroup), chunks on the prefill-shaped kernel. `out` starts as NaN: a head nobody wrote would show."""
+    Hq, Hkv, D = geom
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 1, 31, 32, 100, 257], q_lens=[1] * 6, splits=1, kv8=kv8)
+    B = 1024 // Hkv + 3
+    ctx = torch.randint(0, 150, (B,), generator=torch.Generator().manual_seed(Hq)).tolist()
+    ctx[:4] = [0, 31, 32, 33]
+    _attn_case(K, Hq, Hkv, D, ctx_lens=ctx, q_lens=[1] * B, splits=1, seed=1, kv8=kv8)
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[5, 700, 64, 333], q_lens=[1] * 4, splits=4, seed=2, kv8=kv8)
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 0, 40, 96], q_lens=[77, 5, 33, 64], splits=1, seed=3, kv8=kv8)
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[130, 0], q_lens=[20, 50], splits=2, seed=4, kv8=kv8)
+    _attn_case(K, Hq, Hkv, D, ctx_lens=[0, 300, 37], q_lens=[300, 150, 3], splits=1, seed=5, kv8=kv8)
+
+
 def test_attention_prefill_chunk_splitkv_norope(K):
     _attn_case(K, 12, 12, 64, ctx_lens=[130, 0], q_lens=[20, 50], splits=2, use_rope=False)
 

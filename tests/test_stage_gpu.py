@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 
 
 def gpu_spec(family):
-    if family in ("llama", "qwen2", "llama-attention-bias"):
+    if family in ("llama", "qwen2", "llama-attention-bias", "llama-gqa3"):
         # Llama-family dialects: biases on q/k/v (Qwen2), on q/k/v and o (Llama with attention_bias)
         extra = {"qwen2": dict(hf_type="qwen2", qkv_bias=True, tie_embeddings=True),
-                 "llama-attention-bias": dict(qkv_bias=True, o_bias=True)}.get(family, {})
-        return tiny_spec("llama", hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
-                         intermediate_size=512, vocab_size=320, num_layers=3, **extra)
+                 "llama-attention-bias": dict(qkv_bias=True, o_bias=True),
+                 "llama-gqa3": dict(hidden_size=384, num_heads=6, num_kv_heads=2)}.get(family, {})      # 3 query heads per kv head
+        return tiny_spec("llama", **{**dict(hidden_size=256, num_heads=4, num_kv_heads=2, head_dim=64,
+                                            intermediate_size=512, vocab_size=320, num_layers=3), **extra})
     return tiny_spec("gpt2", hidden_size=256, num_heads=4, num_kv_heads=4, head_dim=64,
                      intermediate_size=1024, vocab_size=333, num_layers=3)
 
@@ -41,7 +42,7 @@ def close(a, b, what):
     assert err <= 0.05 * scale + 0.02, f"{what}: max err {err:.4f} vs scale {scale:.4f}"
 
 
-@pytest.mark.parametrize("family", ["llama", "gpt2", "qwen2", "llama-attention-bias"])
+@pytest.mark.parametrize("family", ["llama", "gpt2", "qwen2", "llama-attention-bias", "llama-gqa3"])
 def test_prefill_and_eager_decode_match_reference(family):
     spec, ref, gpu = build(family, use_graphs=False)
     torch.manual_seed(0)
@@ -67,7 +68,7 @@ def test_prefill_and_eager_decode_match_reference(family):
 
 
 @pytest.mark.parametrize("family,kv_dtype", [("llama", "bf16"), ("llama", "fp8"), ("gpt2", "bf16"), ("gpt2", "fp8"),
-                                             ("qwen2", "bf16"), ("llama-attention-bias", "fp8")])
+                                             ("qwen2", "bf16"), ("llama-attention-bias", "fp8"), ("llama-gqa3", "bf16")])
 def test_long_prompt_in_chunks_matches_reference_in_one_piece(family, kv_dtype):
     """A 300-token prompt prefilled as chunks of 160 + 140 tokens (each more than 128 query columns per
     sequence, so both run on the prefill-shaped attention kernel, the second one over the cached context
@@ -105,7 +106,7 @@ def test_long_prompt_in_chunks_matches_reference_in_one_piece(family, kv_dtype):
         ctx = [c + 1 for c in ctx]
 
 
-@pytest.mark.parametrize("family", ["llama", "gpt2", "qwen2", "llama-attention-bias"])
+@pytest.mark.parametrize("family", ["llama", "gpt2", "qwen2", "llama-attention-bias", "llama-gqa3"])
 def test_graph_decode_matches_reference_greedy(family):
     spec, ref, gpu = build(family, use_graphs=True)
     torch.manual_seed(1)
