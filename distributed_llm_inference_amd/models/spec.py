@@ -20,12 +20,20 @@ from typing import Optional, Dict, Any
 
 @dataclass(frozen=True)
 class RopeScaling:
-    """Llama-3.1 style frequency rescaling (``rope_scaling`` with ``rope_type: llama3``)."""
+    """``rope_scaling`` of a config.json. ``llama3``: Llama-3.1 frequency-dependent rescale (uses
+    ``low_freq_factor`` / ``high_freq_factor``). ``linear``: positions divided by ``factor``. ``yarn``:
+    interpolated below / extrapolated above a band of frequencies set by ``beta_fast`` / ``beta_slow``,
+    cos and sin scaled by ``attention_factor`` (default 0.1 ln(factor) + 1). All of them are static, i.e. a
+    table per stage; ``dynamic`` (a base that depends on the running sequence length) is refused."""
     factor: float = 8.0
     low_freq_factor: float = 1.0
     high_freq_factor: float = 4.0
     original_max_position_embeddings: int = 8192
     rope_type: str = "llama3"
+    beta_fast: float = 32.0
+    beta_slow: float = 1.0
+    attention_factor: Optional[float] = None
+    truncate: bool = True
 
 
 @dataclass(frozen=True)
@@ -134,6 +142,8 @@ class ModelSpec:
         mt = cfg.get("model_type", "")
         archs = cfg.get("architectures") or []
         if mt == "gpt2" or any("GPT2" in a for a in archs):
+            if cfg.get("activation_function", "gelu_new") != "gelu_new" or cfg.get("scale_attn_by_inverse_layer_idx"):
+                raise ValueError("GPT-2 variants other than gelu_new MLPs with plain 1/sqrt(d) attention scaling are not supported")
             h = cfg.get("n_embd", cfg.get("hidden_size"))
             nh = cfg.get("n_head", cfg.get("num_attention_heads"))
             inner = cfg.get("n_inner") or 4 * h
@@ -153,7 +163,14 @@ class ModelSpec:
                 bos_token_id=cfg.get("bos_token_id"),
                 eos_token_id=_scalar_eos(cfg.get("eos_token_id")),
             )
-        if mt in ("llama", "mistral", "qwen2") or any("Llama" in a for a in archs) or "num_key_value_heads" in cfg:
+        # (a config.json without model_type that has the Llama keys is taken as Llama; a NAMED other architecture is
+        # refused rather than run as if it were one: Gemma, Phi, ... differ in norms, activations and scalings)
+        if mt in ("llama", "mistral", "qwen2") or any(a.startswith(("Llama", "Mistral", "Qwen2For")) for a in archs) \
+                or (not mt and not archs and "num_key_value_heads" in cfg):
+            if cfg.get("hidden_act", "silu") not in ("silu", "swish"):
+                raise ValueError(f"hidden_act {cfg.get('hidden_act')!r} is not supported (the fused MLP epilogue is SiLU-gated)")
+            if float(cfg.get("partial_rotary_factor", 1.0)) != 1.0:
+                raise ValueError("partial rotary embeddings are not supported")
             h = cfg["hidden_size"]
             nh = cfg["num_attention_heads"]
             rs = cfg.get("rope_scaling")
@@ -165,13 +182,30 @@ class ModelSpec:
                 if rp.get("rope_type", "default") not in ("default", None):
                     rs = rp
             scaling = None
-            if isinstance(rs, dict) and rs.get("rope_type", rs.get("type")) == "llama3":
+            rtype = rs.get("rope_type", rs.get("type")) if isinstance(rs, dict) else None
+            if rtype == "llama3":
                 scaling = RopeScaling(
                     factor=float(rs.get("factor", 8.0)),
                     low_freq_factor=float(rs.get("low_freq_factor", 1.0)),
                     high_freq_factor=float(rs.get("high_freq_factor", 4.0)),
                     original_max_position_embeddings=int(rs.get("original_max_position_embeddings", 8192)),
                 )
+            elif rtype == "linear":
+                scaling = RopeScaling(factor=float(rs["factor"]), rope_type="linear",
+                                      original_max_position_embeddings=int(cfg.get("max_position_embeddings", 2048)))
+            elif rtype == "yarn":
+                if rs.get("mscale") or rs.get("mscale_all_dim"):
+                    raise ValueError("yarn rope_scaling with mscale / mscale_all_dim is not supported")
+                orig = int(rs.get("original_max_position_embeddings") or cfg.get("max_position_embeddings", 2048))
+                factor = rs.get("factor")
+                scaling = RopeScaling(
+                    factor=float(factor if factor is not None else cfg.get("max_position_embeddings", orig) / orig),
+                    rope_type="yarn", original_max_position_embeddings=orig,
+                    beta_fast=float(rs.get("beta_fast") or 32.0), beta_slow=float(rs.get("beta_slow") or 1.0),
+                    attention_factor=(float(rs["attention_factor"]) if rs.get("attention_factor") is not None else None),
+                    truncate=bool(rs.get("truncate", True)))
+            elif rtype not in (None, "default"):
+                raise ValueError(f"rope_scaling type {rtype!r} is not supported (llama3, linear and yarn are)")
             if cfg.get("mlp_bias"):
                 raise ValueError("mlp_bias=true is not supported (the fused gate/up epilogue has no bias)")
             hf_type = mt if mt in ("mistral", "qwen2") else "llama"
@@ -257,11 +291,20 @@ class ModelSpec:
             raise ValueError("a Llama config.json has one `attention_bias` for q/k/v and o alike")
         if self.rope_scaling is not None:
             rs = self.rope_scaling
-            cfg["rope_scaling"] = {
-                "rope_type": "llama3", "factor": rs.factor, "low_freq_factor": rs.low_freq_factor,
-                "high_freq_factor": rs.high_freq_factor,
-                "original_max_position_embeddings": rs.original_max_position_embeddings,
-            }
+            if rs.rope_type == "linear":
+                cfg["rope_scaling"] = {"rope_type": "linear", "factor": rs.factor}
+            elif rs.rope_type == "yarn":
+                cfg["rope_scaling"] = {"rope_type": "yarn", "factor": rs.factor, "beta_fast": rs.beta_fast, "beta_slow": rs.beta_slow,
+                                       "original_max_position_embeddings": rs.original_max_position_embeddings,
+                                       "truncate": rs.truncate}
+                if rs.attention_factor is not None:
+                    cfg["rope_scaling"]["attention_factor"] = rs.attention_factor
+            else:
+                cfg["rope_scaling"] = {
+                    "rope_type": "llama3", "factor": rs.factor, "low_freq_factor": rs.low_freq_factor,
+                    "high_freq_factor": rs.high_freq_factor,
+                    "original_max_position_embeddings": rs.original_max_position_embeddings,
+                }
         return cfg
 
 

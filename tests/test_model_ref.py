@@ -60,6 +60,39 @@ def test_ref_llama3_rope_scaling_matches_transformers():
     assert torch.allclose(got, want, atol=3e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("kind", ["linear", "yarn", "yarn-attention-factor"])
+def test_ref_linear_and_yarn_rope_scaling_match_transformers(kind):
+    from distributed_llm_inference_amd.models.spec import ModelSpec, RopeScaling
+    rs = {"linear": RopeScaling(factor=4.0, rope_type="linear", original_max_position_embeddings=512),
+          "yarn": RopeScaling(factor=4.0, rope_type="yarn", original_max_position_embeddings=64),
+          "yarn-attention-factor": RopeScaling(factor=8.0, rope_type="yarn", original_max_position_embeddings=48,
+                                               beta_fast=16.0, beta_slow=2.0, attention_factor=1.3)}[kind]
+    spec = tiny_spec("llama", rope_scaling=rs, max_position=512)
+    assert ModelSpec.from_hf_config(spec.hf_config(), name=spec.name) == spec
+    hf = hf_model_from(spec, seed=1)
+    plan = make_plans(spec, 1)[0]
+    st = RefStage(spec, plan, random_stage_weights(spec, plan, seed=1))
+    ids = torch.randint(3, spec.vocab_size, (1, 200))
+    with torch.no_grad():
+        want = hf(ids).logits[0, -1]
+    got = st.forward(step([5], [200], [0]), ids[0])[0]
+    assert torch.allclose(got, want, atol=3e-4, rtol=1e-4)
+
+
+def test_unsupported_rope_scaling_is_refused():
+    from distributed_llm_inference_amd.models.spec import ModelSpec
+    cfg = {**tiny_spec("llama").hf_config(), "rope_scaling": {"rope_type": "dynamic", "factor": 2.0}}
+    with pytest.raises(ValueError, match="dynamic"):
+        ModelSpec.from_hf_config(cfg)
+    # architectures that merely look like Llama (same keys) are refused, as are activations the fused MLP does not compute
+    base = tiny_spec("llama").hf_config()
+    with pytest.raises(ValueError, match="unsupported model_type"):
+        ModelSpec.from_hf_config({**base, "model_type": "gemma", "architectures": ["GemmaForCausalLM"]})
+    with pytest.raises(ValueError, match="hidden_act"):
+        ModelSpec.from_hf_config({**base, "hidden_act": "gelu"})
+    assert ModelSpec.from_hf_config({k: v for k, v in base.items() if k not in ("model_type", "architectures")}).is_llama
+
+
 def test_ref_ragged_batch_equals_single():
     spec = tiny_spec("llama")
     plan = make_plans(spec, 1)[0]
