@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import json
 import os
-from dataclasses import dataclass, asdict
+from dataclasses import dataclass, asdict, replace
 from typing import Optional, Dict, Any
 
 
@@ -54,6 +54,9 @@ class ModelSpec:
     tie_embeddings: bool = False
     bos_token_id: Optional[int] = None
     eos_token_id: Optional[int] = None
+    # further end-of-sequence ids (config.json / generation_config.json may list several: Llama-3-Instruct ends a
+    # turn with <|eot_id|>, not with the id listed first)
+    extra_eos_token_ids: tuple = ()
     # Llama-family variants: which config.json dialect the spec came from ("llama" | "mistral" | "qwen2"),
     # biases on the q/k/v projections (Qwen2; Llama with `attention_bias`) and on the output projection
     # (Llama with `attention_bias`), and the attention window of checkpoints trained with one (Mistral)
@@ -232,6 +235,7 @@ class ModelSpec:
                 tie_embeddings=bool(cfg.get("tie_word_embeddings", False)),
                 bos_token_id=cfg.get("bos_token_id"),
                 eos_token_id=_scalar_eos(cfg.get("eos_token_id")),
+                extra_eos_token_ids=_more_eos(cfg.get("eos_token_id")),
                 hf_type=hf_type,
                 qkv_bias=True if hf_type == "qwen2" else attn_bias,       # Qwen2: q/k/v always biased, o never
                 o_bias=False if hf_type == "qwen2" else attn_bias,
@@ -251,7 +255,19 @@ class ModelSpec:
         cfg_path = os.path.join(path_or_name, "config.json")
         if os.path.isfile(cfg_path):
             with open(cfg_path) as f:
-                return ModelSpec.from_hf_config(json.load(f), name=path_or_name)
+                spec = ModelSpec.from_hf_config(json.load(f), name=path_or_name)
+            # generation_config.json may name more end-of-sequence ids than config.json does
+            gen_path = os.path.join(path_or_name, "generation_config.json")
+            if os.path.isfile(gen_path):
+                with open(gen_path) as f:
+                    ge = json.load(f).get("eos_token_id")
+                ids = [int(x) for x in (ge if isinstance(ge, (list, tuple)) else [ge] if ge is not None else [])]
+                more = tuple(dict.fromkeys(x for x in (*spec.extra_eos_token_ids, *ids) if x != spec.eos_token_id))
+                if spec.eos_token_id is None and more:
+                    spec = replace(spec, eos_token_id=more[0], extra_eos_token_ids=more[1:])
+                else:
+                    spec = replace(spec, extra_eos_token_ids=more)
+            return spec
         raise FileNotFoundError(
             f"{path_or_name!r} is neither a built-in model ({sorted(BUILTIN_SPECS)}) "
             f"nor a directory with config.json (the Hugging Face hub is not reachable)")
@@ -289,6 +305,8 @@ class ModelSpec:
             del cfg["attention_bias"], cfg["mlp_bias"]
         elif self.qkv_bias != self.o_bias:
             raise ValueError("a Llama config.json has one `attention_bias` for q/k/v and o alike")
+        if self.extra_eos_token_ids:
+            cfg["eos_token_id"] = [self.eos_token_id, *self.extra_eos_token_ids]
         if self.rope_scaling is not None:
             rs = self.rope_scaling
             if rs.rope_type == "linear":
@@ -312,6 +330,10 @@ def _scalar_eos(v):
     if isinstance(v, (list, tuple)):
         return v[0] if v else None
     return v
+
+
+def _more_eos(v) -> tuple:
+    return tuple(int(x) for x in v[1:]) if isinstance(v, (list, tuple)) else ()
 
 
 # Shapes of the benchmark models.  The reference serves TinyLlama-1.1B-Chat

@@ -81,6 +81,7 @@ class Request:
     prompt_ids: List[int]
     params: SamplingParams
     eos_id: Optional[int]
+    stop_ids: frozenset = frozenset()     # every id that ends the sequence (eos_id and the spec's further ones)
     t_arrival: float = field(default_factory=time.perf_counter)
     state: str = "waiting"            # waiting | prefill | running | finished | failed
     mb: int = -1
@@ -234,7 +235,8 @@ class Engine:
         eos = getattr(self.tok, "eos_token_id", None)
         if eos is None:
             eos = self.spec.eos_token_id
-        req = Request(rid=rid, prompt_ids=list(prompt_ids), params=params, eos_id=eos)
+        stop = frozenset(i for i in (eos, *getattr(self.spec, "extra_eos_token_ids", ())) if i is not None)
+        req = Request(rid=rid, prompt_ids=list(prompt_ids), params=params, eos_id=eos, stop_ids=stop)
         req.context = req.prompt_ids
         req.seed = params.seed if params.seed is not None else (time.time_ns() ^ (rid * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
         if self.fatal:
@@ -800,7 +802,7 @@ class Engine:
         elif r.token_times:
             self.latencies.append(now - r.token_times[-1])
             self.hist_itl.observe(now - r.token_times[-1])
-        if r.params.stop_on_eos and r.eos_id is not None and tok == r.eos_id:
+        if r.params.stop_on_eos and tok in r.stop_ids:
             self._finish(r, now)          # EOS is not emitted (orchestration.py:181-183)
             return
         r.output.append(tok)

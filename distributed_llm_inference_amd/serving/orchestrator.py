@@ -331,6 +331,7 @@ class HttpRelayBackend:
             n = max(1, min(int(max_new_tokens), self.cfg.max_tokens_cap))
             generated: List[int] = []
             eos = getattr(self.tok, "eos_token_id", None)
+            stop = {i for i in (eos, *getattr(self.spec, "extra_eos_token_ids", ())) if i is not None}
             cached = 0
             debug = []
             gen = None
@@ -350,7 +351,7 @@ class HttpRelayBackend:
                 if self.cfg.debug_top5 and step < 3:                                      # orchestration.py:172-178
                     debug.append(top_candidates(logits, temperature, top_k, top_p, 5))
                 nxt = sample_token(logits, temperature, top_k, top_p, generator=gen)
-                if eos is not None and nxt == eos:
+                if nxt in stop:
                     break
                 ids = ids + [nxt]
                 generated.append(nxt)

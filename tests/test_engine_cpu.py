@@ -153,6 +153,14 @@ def test_eos_stops_without_emitting_and_token_cap():
         assert r.output == free_run[:first] and eos not in r.output
         r2 = pipe.engine.submit(p, greedy(3)).wait(60)
         assert len(r2.output) == 3
+        # a model with several end-of-sequence ids (config.json / generation_config.json lists, e.g. an end-of-turn
+        # token): any of them ends the sequence, none is emitted
+        import dataclasses
+        pipe.engine.tok.eos_token_id = 2
+        other = next(t for t in free_run[2:] if t != 2)
+        pipe.engine.spec = dataclasses.replace(pipe.engine.spec, extra_eos_token_ids=(999999, other))
+        r3 = pipe.engine.submit(p, SamplingParams(temperature=0.0, max_new_tokens=12)).wait(60)
+        assert r3.output == free_run[:free_run.index(other)] and other not in r3.output
     finally:
         pipe.close()
 

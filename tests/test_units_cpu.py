@@ -229,6 +229,24 @@ def test_stage_loader_reads_only_its_tensors(tmp_path, family):
         rd.close()
 
 
+def test_end_of_sequence_ids_from_config_and_generation_config(tmp_path):
+    import json
+    from distributed_llm_inference_amd.models.spec import ModelSpec
+    cfg = tiny_spec("llama").hf_config()
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({**cfg, "eos_token_id": [7, 9]}))
+    s = ModelSpec.from_pretrained(str(d))
+    assert s.eos_token_id == 7 and s.extra_eos_token_ids == (9,)
+    assert ModelSpec.from_hf_config(s.hf_config(), name=s.name) == s
+    (d / "generation_config.json").write_text(json.dumps({"eos_token_id": [7, 11, 9]}))
+    s = ModelSpec.from_pretrained(str(d))
+    assert s.eos_token_id == 7 and s.extra_eos_token_ids == (9, 11)
+    (d / "config.json").write_text(json.dumps({**cfg, "eos_token_id": None}))
+    s = ModelSpec.from_pretrained(str(d))
+    assert s.eos_token_id == 7 and s.extra_eos_token_ids == (11, 9)
+
+
 def test_safetensors_rejects_corrupt_header(tmp_path):
     p = tmp_path / "x.safetensors"
     save_safetensors({"a": torch.arange(6, dtype=torch.float32).reshape(2, 3), "b": torch.ones(4, dtype=torch.bfloat16)}, str(p))
