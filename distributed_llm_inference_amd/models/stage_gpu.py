@@ -530,7 +530,7 @@ class GpuStage:
         # The lm_head GEMM (tile kernel above 256 rows, weight-streaming kernels up to there) also leaves the maximum
         # of every 32-column chunk of every row, and the sampler reads the logits only where a top-k candidate can be
         # (a few KB of a 513 KB row).
-        wk.guided = wk.cmax is not None and self.vocab_pad % 4 == 0 and s.vocab_size <= 131072 and self._guided_ok
+        wk.guided = wk.cmax is not None and self.vocab_pad % 4 == 0 and s.vocab_size <= 262144 and self._guided_ok
         if wk.guided:
             K.gemm_head(wk.logits[:R], wk.cmax[:R], hx, self.lm_head, wk.ws, self.vocab_pad, s.vocab_size)
         else:

@@ -92,7 +92,7 @@ long dlia_paged_attention_ws_floats(int B, int max_q_len, int Hq, int Hkv, int D
 // One token per row from fp32 logits [R, ldl] with temperature / top-k / top-p and a
 // counter-based RNG keyed by (seed[r], step[r]); temperature <= 0 -> argmax.
 // chunk_max (optional): per row the maximum of every 32-column chunk of its logits (row stride ldc, at most
-// 4096 chunks), as the lm_head GEMM writes them; the row is then read only where a candidate can be.
+// 8192 chunks), as the lm_head GEMM writes them; the row is then read only where a candidate can be.
 void dlia_sample(int* out_tokens, const float* logits, const float* temperature,
                  const int* top_k, const float* top_p, const uint64_t* seeds,
                  const int* steps, int R, int vocab, long ldl, float* dbg_probs,

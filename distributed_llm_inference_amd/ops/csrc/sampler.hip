@@ -27,7 +27,7 @@
 // the k-th largest chunk maximum is a lower bound of the k-th largest logit — each of the k chunks
 // at or above it holds at least one value at or above it — so every top-k candidate lies in a chunk
 // whose maximum reaches that bound. The kernel selects that bound exactly (radix select over the <=
-// 4096 maxima in LDS), reads only those chunks (k x 32 values instead of the whole row: 6 KB of a
+// 8192 maxima in LDS), reads only those chunks (k x 32 values instead of the whole row: 6 KB of a
 // 513 KB row at k = 50, vocabulary 128256) and hands the values at or above the bound to the same
 // sort / cut / draw as before: same candidates or a superset, hence the same token. Greedy rows read
 // one chunk. Tie patterns that overflow the lists fall back to the whole-row methods.
@@ -40,7 +40,7 @@ namespace dlia {
 constexpr int kSampThreads = 1024;
 constexpr int kCap = 1024;            // candidates the sorted path holds in LDS; larger / absent k takes the full-row path
 constexpr int kChunk = 32;            // columns per chunk maximum (gemm_pingpong.hip: one wave's columns of a column half)
-constexpr int kMaxChunks = 4096;      // chunk maxima a row may have (vocabulary <= 131072)
+constexpr int kMaxChunks = 8192;      // chunk maxima a row may have (vocabulary <= 262144: Qwen2's 151,936 / 152,064 fit)
 constexpr int kHotCap = 1024;         // chunks that may reach the bound before the whole-row method takes over
 
 __device__ __forceinline__ unsigned f2key(float f) {

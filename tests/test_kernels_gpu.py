@@ -815,7 +815,7 @@ def _chunk_max(logits, V):
     return padded.view(R, nch, 32).amax(2).contiguous()
 
 
-@pytest.mark.parametrize("V", [32000, 50257, 128256])
+@pytest.mark.parametrize("V", [32000, 50257, 128256, 151936])
 def test_guided_sampler_draws_the_same_tokens_as_the_whole_row_sampler(K, V):
     """With the chunk maxima the sampler reads only the chunks that can hold a candidate; the tokens must
     be those of the whole-row method for every rule: k = 1 / 5 / 50 / 1024, greedy, rows of exact ties
@@ -852,7 +852,7 @@ def test_guided_sampler_draws_the_same_tokens_as_the_whole_row_sampler(K, V):
     assert want[6] == V - 1 and want[7] == logits[7, :V].argmax().item()
 
 
-@pytest.mark.parametrize("V", [320, 32000, 50257, 128256])
+@pytest.mark.parametrize("V", [320, 32000, 50257, 128256, 151936])
 def test_sampler_matches_reference_filter(K, V):
     torch.manual_seed(3)
     R = 6
