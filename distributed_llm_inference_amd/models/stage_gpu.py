@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -104,6 +105,14 @@ class _MicroBatchState:
     graph: Optional[torch.cuda.CUDAGraph] = None
     splits: int = 1              # split-KV factor the captured step was built with
     splits_wanted: int = 1       # split-KV factor the current composition calls for (re-capture when it differs)
+
+
+# One capture at a time per process. Entering a capture empties the allocator's cache (`hipFree`, which waits
+# for the device) and collects garbage; with several stages in ONE process (in-process pipelines: tests,
+# `LocalPipeline`) a second stage thread doing that while the first is mid-capture invalidated the first's
+# capture now and then (`hipErrorStreamCaptureInvalidated` at capture end, the stage's engine then fails every
+# request). A stage process of a real pipeline holds one stage: the lock is never contended there.
+_CAPTURE_LOCK = threading.Lock()
 
 
 class GpuStage:
@@ -753,22 +762,23 @@ class GpuStage:
         # Warm up on a side stream (first-use initialisation must not happen under capture), then
         # capture. The captured step advances ctx/steps (and, on a single-stage pipeline, feeds its
         # tokens back into ids), so save and restore them around both.
-        saved = (st.ctx.clone(), st.steps.clone(), st.ids.clone())
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            self._decode_body(st)
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
-        g = torch.cuda.CUDAGraph()
-        # Thread-local capture mode: only this thread issues the captured work, but a stage process
-        # of a multi-GPU pipeline also runs RCCL's watchdog thread (event queries at any time), and
-        # under the default global mode a HIP call from another thread invalidates the capture.
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            self._decode_body(st)
-        st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
-        st.graph = g
-        self.graph_captures += 1
+        with _CAPTURE_LOCK:
+            saved = (st.ctx.clone(), st.steps.clone(), st.ids.clone())
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self._decode_body(st)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
+            g = torch.cuda.CUDAGraph()
+            # Thread-local capture mode: only this thread issues the captured work, but a stage process
+            # of a multi-GPU pipeline also runs RCCL's watchdog thread (event queries at any time), and
+            # under the default global mode a HIP call from another thread invalidates the capture.
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._decode_body(st)
+            st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
+            st.graph = g
+            self.graph_captures += 1
 
     # ---- introspection ----------------------------------------------------------------------
     def memory_report(self) -> Dict[str, float]:

@@ -178,6 +178,14 @@ class LocalPipeline:
 
     def close(self):
         self.engine.stop()
+        if self.engine.fatal is not None and len(self.runtimes) > 1:
+            # after a fatal error the engine does not drain its stages (they may be the ones that hang); stage
+            # THREADS that are still responsive are told to stop all the same, or they would outlive the pipeline
+            try:
+                from ..runtime.batch import KIND_SHUTDOWN, control
+                self.runtimes[0].links.next_ctrl.put(control(KIND_SHUTDOWN).to_bytes())
+            except Exception:
+                pass
         for t in self.threads:
             t.join(5.0)
         self.runtimes[0].dump_trace()
