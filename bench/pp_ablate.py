@@ -1,5 +1,6 @@
 """Ablation timing of the 256 x 256 ping-pong GEMM: diagnostic builds of gemm_pingpong.hip with parts
-of the main loop left out (PP_ABL mask: 1 DMA issue, 2 fragment reads, 4 barriers, 8 MFMAs), timed on
+of the main loop left out (PP_ABL mask: 1 DMA issue, 2 fragment reads, 4 barriers, 8 MFMAs; for the four-wave
+kernel, selected with DLIA_GEMM_LARGE=quad: 64 landing waits, 128 barriers, 256 DMA issue), timed on
 the Llama-3-8B layer shapes. The outputs of an ablated build are wrong on purpose; the times say what
 the remaining parts cost. Build on the CPU box first (`--build`), run on the GPU.
 
@@ -66,9 +67,12 @@ def main():
             L = C.CDLL(so_path(mask))
             f = L.dlia_gemm_large
             f.restype = None
+            # (out, x, wp, bias, residual, workspace, ws_floats, M, N, K, ldx, ldo, ldr, epi, out_f32, wg_target, stream,
+            #  chunk_max, ldc, n_valid): every argument of the C signature is listed — an argument left out is read as
+            # whatever the register holds, and a stray `chunk_max` pointer is written through
             f.argtypes = [vp, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
-                          C.c_int, C.c_int, C.c_int, vp]
-            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile"), (32, "stamps")) if mask & b) + ")"]
+                          C.c_int, C.c_int, C.c_int, vp, vp, C.c_long, C.c_int]
+            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile"), (32, "stamps"), (64, "q:noWAIT"), (128, "q:noBAR"), (256, "q:noDMA")) if mask & b) + ")"]
             tt, tf = 0.0, 0.0
             for name, N, K in shapes:
                 x, wp, out = data[name]
@@ -78,7 +82,7 @@ def main():
 
                 def run():
                     f(out.data_ptr(), x.data_ptr(), wp.data_ptr(), None, None, stamps.data_ptr() if stamps is not None else None,
-                      0, M, N, K, K + pad, N, 0, 0, 0, 0, vp(st))
+                      0, M, N, K, K + pad, N, 0, 0, 0, 0, vp(st), None, 0, 0)
                 for _ in range(3):
                     run()
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

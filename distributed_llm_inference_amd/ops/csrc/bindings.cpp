@@ -211,10 +211,11 @@ int64_t gemm_ws_floats(int64_t M, int64_t N, int64_t K) {
 }
 
 int64_t large_gemm_kernel(int64_t which) {
-  DLIA_CHECK(which == 0 || which == 2 || which == 4, "large_gemm_kernel: 0 ping-pong (default), 2 stream, 4 stream with narrow row blocks");
+  DLIA_CHECK(which == 0 || which == 2 || which == 4 || which == 6,
+             "large_gemm_kernel: 0 ping-pong (default), 2 stream, 4 stream with narrow row blocks, 6 four-wave 256 x 256");
   const int narrow_before = dlia_gemm_rows_set_narrow(which == 4 ? 1 : 0);
-  const int before = dlia_gemm_large_choice(which == 4 ? 2 : (int)which);
-  return before == 2 && narrow_before ? 4 : before;
+  const int before = dlia_gemm_large_choice(which == 4 ? 2 : (which == 6 ? 4 : (int)which));
+  return before == 4 ? 6 : (before == 2 && narrow_before ? 4 : before);
 }
 
 // out[M, N_out] = epi(x[M,K] @ W^T); wp = packed weights (uint8 view of the packed image).

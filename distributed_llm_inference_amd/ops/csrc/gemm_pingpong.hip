@@ -403,14 +403,242 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
       write_acc_tiles<4, 2, true>(p, acc[hm][hn], cb * 16 + hn * 8 + wc * 2, l15, quad, 0, mrow0 + hm * 128 + wr * 64);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same 256 x 256 tile with FOUR waves, one per SIMD, each owning 128 x 128 of it (64 rows of
+// each row half x 64 columns of each column half): 256 accumulator registers per lane, and per
+// K-tile 32 fragment reads for 128 MFMAs per wave instead of 24 for 64 — a third fewer LDS bytes
+// per MFMA — and two barriers per 128 MFMAs instead of two per 16. No partner wave hides anything
+// here: a phase first issues the LDS reads of a LATER phase's new operand, then its own 16 MFMAs,
+// whose operands arrived during earlier phases.
+//
+// The unit is a K-slice of 32 (one MFMA k-step): four fragment sets (A0, A1, B0, B1: 16 registers
+// each) and an order of quadrants that alternates between the even and the odd slice of a K-tile
+// make "load one set while two others are multiplied" work out with no set loaded while in use:
+//   slice kk = 0: A0B0 [load B1]  A0B1 [load A1]  A1B1 [load A0 of kk = 1]       A1B0 [load B1 of kk = 1]
+//   slice kk = 1: A0B1 [load B0]  A0B0 [load A1]  A1B0 [load A0 of the next tile] A1B1 [load B0 of the next tile]
+// Phase j = 4 kk + q of K-tile T: half-tiles of T + 1 are first read at j = 6 (A0), 7 (B0), 8 (B1), 9 (A1);
+// those of T are last read at j = 2 (A0), 3 (B1), 4 (B0), 5 (A1), each consumed by the MFMAs one or
+// two phases later. The DMA stream is A1 B1 of T + 1, A0 B0 of T + 2, one half-tile (four 1 KiB pieces
+// per wave, one ahead of each group of four MFMAs) in each odd phase:
+//  * write-after-read: every refill is issued at least two phases after the last read of its slot's
+//    previous content, behind one of the two barriers of a K-tile (start of phases 5 and 7).
+//  * read-after-write: before the barrier of phase 5 every wave waits until only the two half-tiles
+//    issued last may be in flight (A0, B0 of T + 1 have landed), before the one of phase 7 until only
+//    one may be (B1, A1 of T + 1 have landed).
+// bf16, no K split. Measured against the eight-wave kernel above (same box, 4096 rows, Llama-3-8B shapes): down
+// projection (K 14336, one round of 256 workgroups) 1.49 against 1.45-1.47 PFLOP/s, gate/up (K 4096, seven rounds)
+// 1.29-1.30 against 1.39-1.41: the main loop is a little faster, the serial prologue / epilogue of a workgroup whose
+// four waves each own 64 output tiles costs more than that at short K. Ablations: without barriers and landing waits
+// +2.4 %, without the DMA +18-20 % — the global -> LDS traffic, not the fragment reads or the synchronisation, is what
+// both kernels pay for. The eight-wave kernel stays the default; DLIA_GEMM_LARGE=quad selects this one.
+constexpr int kQThreads = 256;
+
+// One 1 KiB piece global -> LDS in the scalar-base form: address = base (SGPR pair, wave-uniform) + a 32-bit lane
+// offset + the instruction's immediate, which also advances the LDS address from M0. A lone wave per SIMD issues its
+// own DMA between its MFMAs; with a scalar base the per-tile address arithmetic is scalar, no vector instruction is
+// spent on 64-bit lane addresses (measured: same time as with per-lane pointers — it is the transfers that cost,
+// not their issue). FIRST: sets M0 for the four pieces of a half-tile.
+template <int E, bool FIRST>
+__device__ __forceinline__ void q_dma_piece(const void* sbase, unsigned voff, unsigned lds_addr) {
+  if constexpr (FIRST)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                 :: "s"(lds_addr), "v"(voff), "s"(sbase), "n"(E * 1024) : "memory", "m0");
+  else
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" :: "v"(voff), "s"(sbase), "n"(E * 1024) : "memory");
+}
+
+// The accumulators are pinned to the accumulation registers ("a" constraint): left to itself hipcc keeps part of the
+// 256 in ordinary registers, runs out of those, and shuttles values between the two files around every MFMA (600
+// copies and 90 spills per K-tile pair). Within the loop no MFMA reads an accumulator that one of the previous 100+
+// MFMAs wrote, so no wait states are owed between them; the epilogue waits explicitly before it reads them.
+__device__ __forceinline__ void mfma16_acc(f32x4& c, const u32x4& a, const u32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// The first product into an accumulator (C = 0): the accumulators are never initialised through ordinary registers.
+__device__ __forceinline__ void mfma16_acc_first(f32x4& c, const u32x4& a, const u32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+
+// Accumulator -> ordinary registers, one tile at a time and in program order (volatile): left to the compiler, all 256
+// are copied out at once after the loop, and the 256 ordinary registers that takes push everything else into scratch.
+__device__ __forceinline__ f32x4 acc_read(f32x4 c) {
+  float x0, x1, x2, x3;
+  asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+               : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "a"(c[0]), "a"(c[1]), "a"(c[2]), "a"(c[3]));
+  return f32x4{x0, x1, x2, x3};
+}
+
+__global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, quad = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int mblocks = (p.M + 255) >> 8;
+  const int nb = (p.ntiles + 15) >> 4;
+  const int within = blockIdx.x >> 3;
+  const int cb = (within / mblocks) * 8 + (blockIdx.x & 7);
+  if (cb >= nb) return;
+  const int mblk = within % mblocks, mrow0 = mblk * 256;
+  const int n = p.K >> 6, KT = n * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+
+  // ---- DMA sources: per half-tile this wave moves pieces 4 wave .. 4 wave + 3 --------------------
+  // x piece e: 8 rows x 128 B (rows past M re-read the last row; never stored); weight piece e: (n-tile 2 wave + e / 2,
+  // k-step e % 2), a column half past the packed width re-reads the first one. Lane offsets are relative to a base
+  // that sits 3 KiB low, so that "offset - e KiB" (the immediate adds e KiB back) is never negative.
+  const long ldxb = p.ldx * 2;
+  const char* const abase = reinterpret_cast<const char*>(p.x) + (long)mrow0 * ldxb - 3072;
+  const char* const bbase = reinterpret_cast<const char*>(p.wp) + (long)cb * 16 * KT * 1024 - 3072;
+  unsigned aoff[2][4], boff4[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 32 * wave + 8 * e + (lane >> 3);
+      const int slot = (lane & 7) ^ ((r >> 1) & 7);
+      aoff[h][e] = (unsigned)((long)(min(mrow0 + h * 128 + r, p.M - 1) - mrow0) * ldxb) + slot * 16 + 3072 - e * 1024;
+      const int j = 2 * wave + (e >> 1);
+      const int nt = (cb * 16 + h * 8 + j < p.ntiles) ? h * 8 + j : j;
+      boff4[h][e] = (unsigned)(nt * KT + (e & 1)) * 1024u + lane * 16 + 3072 - e * 1024;
+    }
+  // kind: 0 A0, 1 B0, 2 B1, 3 A1 (the LDS slot within a K-tile's buffer); c = K-tile (its buffer: c & 1); piece e
+  auto issue_piece = [&](auto kind_c, int c, auto e_c) {
+    constexpr int kind = decltype(kind_c)::value, e = decltype(e_c)::value;
+    const int cc = min(c, n - 1);
+    const unsigned dst = lds0 + ((c & 1) * 4 + kind) * kPPHalf + wave * 4096;
+    if constexpr (kind == 0 || kind == 3) q_dma_piece<e, e == 0>(abase + (long)cc * 128, aoff[kind == 3 ? 1 : 0][e], dst);
+    else                                  q_dma_piece<e, e == 0>(bbase + (long)cc * 2048, boff4[kind == 2 ? 1 : 0][e], dst);
+  };
+  auto issue = [&](auto kind_c, int c) {
+    issue_piece(kind_c, c, ic<0>{}); issue_piece(kind_c, c, ic<1>{}); issue_piece(kind_c, c, ic<2>{}); issue_piece(kind_c, c, ic<3>{});
+  };
+
+  f32x4 acc[2][2][4][4];                         // [row half][column half][m-tile][n-tile]; first written by K-slice 0 of K-tile 0
+  u32x4 a0[4], a1[4], b0[4], b1[4];              // fragments of one K-slice
+
+  const int xoff = (wr * 64 + l15) * 128;
+  const int sw = (l15 >> 1) & 7;
+  const int boff = wc * 8192 + lane * 16;
+  // (par, h, kk) -> fragment g of a set: row half h of the x tile / column half h of the weight tile, K-slice kk
+  auto read_a1 = [&](int par, auto half_c, auto kk_c, u32x4 (&af)[4], int g) {
+    constexpr int h = decltype(half_c)::value, kk = decltype(kk_c)::value;
+    af[g] = *reinterpret_cast<const u32x4*>(smem + (par * 4 + (h ? 3 : 0)) * kPPHalf + xoff + (((kk * 4 + quad) ^ sw) << 4) + g * 2048);
+  };
+  auto read_b1 = [&](int par, auto half_c, auto kk_c, u32x4 (&bf)[4], int g) {
+    constexpr int h = decltype(half_c)::value, kk = decltype(kk_c)::value;
+    bf[g] = *reinterpret_cast<const u32x4*>(smem + (par * 4 + (h ? 2 : 1)) * kPPHalf + boff + kk * 1024 + g * 2048);
+  };
+  // Group g of a phase's 16 MFMAs: row g of the quadrant (BYCOL = false) or column g (true) — whichever makes group g
+  // need only fragment g of the set that the previous phase loaded (an A set: rows; a B set: columns), so that a read
+  // issued before group g of one phase is first needed by group g of the next, a whole phase later.
+  auto mfma_group = [&](f32x4 (&c)[4][4], const u32x4 (&af)[4], const u32x4 (&bf)[4], int g, auto bycol_c, auto first_c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = decltype(bycol_c)::value ? u : g, j = decltype(bycol_c)::value ? g : u;
+      if constexpr (decltype(first_c)::value) mfma16_acc_first(c[i][j], bf[j], af[i]);
+      else mfma16_acc(c[i][j], bf[j], af[i]);
+    }
+  };
+
+  // Phase (kk, q) of K-tile t (buffer par = t & 1, a compile-time constant at every call site): four groups of
+  // [one LDS read for a later phase, four MFMAs] — a lone wave pays for a burst of reads ahead of its MFMAs, reads
+  // spread between them are almost free.
+  auto phase = [&](auto par_c, auto kk_c, auto q_c, int t, auto first_c) {
+    constexpr int par = decltype(par_c)::value, kk = decltype(kk_c)::value, q = decltype(q_c)::value;
+    constexpr bool first = decltype(first_c)::value && kk == 0;       // K-slice 0 of K-tile 0
+    constexpr int j = 4 * kk + q;
+    auto rd = [&](int g) {
+      if constexpr (kk == 0) {
+        if constexpr (q == 0) read_b1(par, ic<1>{}, ic<0>{}, b1, g);
+        if constexpr (q == 1) read_a1(par, ic<1>{}, ic<0>{}, a1, g);
+        if constexpr (q == 2) read_a1(par, ic<0>{}, ic<1>{}, a0, g);
+        if constexpr (q == 3) read_b1(par, ic<1>{}, ic<1>{}, b1, g);
+      } else {
+        if constexpr (q == 0) read_b1(par, ic<0>{}, ic<1>{}, b0, g);
+        if constexpr (q == 1) read_a1(par, ic<1>{}, ic<1>{}, a1, g);
+        if constexpr (q == 2) read_a1(par ^ 1, ic<0>{}, ic<0>{}, a0, g);
+        if constexpr (q == 3) read_b1(par ^ 1, ic<0>{}, ic<0>{}, b0, g);
+      }
+    };
+    auto mm = [&](int g) {
+      using F = std::integral_constant<bool, first>;
+      using C = std::integral_constant<bool, (q < 2)>;      // phases 0, 1 follow the load of a B set, phase 2 that of an A set
+      if constexpr (kk == 0) {
+        if constexpr (q == 0) mfma_group(acc[0][0], a0, b0, g, C{}, F{});
+        if constexpr (q == 1) mfma_group(acc[0][1], a0, b1, g, C{}, F{});
+        if constexpr (q == 2) mfma_group(acc[1][1], a1, b1, g, C{}, F{});
+        if constexpr (q == 3) mfma_group(acc[1][0], a1, b0, g, C{}, F{});
+      } else {
+        if constexpr (q == 0) mfma_group(acc[0][1], a0, b1, g, C{}, std::false_type{});
+        if constexpr (q == 1) mfma_group(acc[0][0], a0, b0, g, C{}, std::false_type{});
+        if constexpr (q == 2) mfma_group(acc[1][0], a1, b0, g, C{}, std::false_type{});
+        if constexpr (q == 3) mfma_group(acc[1][1], a1, b1, g, C{}, std::false_type{});
+      }
+    };
+    auto dma = [&](auto e_c) {
+      if constexpr ((j & 1) && !(PP_ABL & 256)) {
+        // stream: ... A1 B1 of t + 1 (phases 1, 3), A0 B0 of t + 2 (phases 5, 7), one piece ahead of each MFMA group
+        if constexpr (j == 1) issue_piece(ic<3>{}, t + 1, e_c);
+        if constexpr (j == 3) issue_piece(ic<2>{}, t + 1, e_c);
+        if constexpr (j == 5) issue_piece(ic<0>{}, t + 2, e_c);
+        if constexpr (j == 7) issue_piece(ic<1>{}, t + 2, e_c);
+      }
+    };
+    if constexpr (j == 5) { if constexpr (!(PP_ABL & 64)) pp_wait_vm<8>(); if constexpr (!(PP_ABL & 128)) pp_barrier(); }   // A0, B0 of t + 1 have landed; their readers of t are done
+    if constexpr (j == 7) { if constexpr (!(PP_ABL & 64)) pp_wait_vm<4>(); if constexpr (!(PP_ABL & 128)) pp_barrier(); }   // B1, A1 of t + 1 have landed
+    rd(0); dma(ic<0>{}); __builtin_amdgcn_sched_barrier(0); mm(0); __builtin_amdgcn_sched_barrier(0);
+    rd(1); dma(ic<1>{}); __builtin_amdgcn_sched_barrier(0); mm(1); __builtin_amdgcn_sched_barrier(0);
+    rd(2); dma(ic<2>{}); __builtin_amdgcn_sched_barrier(0); mm(2); __builtin_amdgcn_sched_barrier(0);
+    rd(3); dma(ic<3>{}); __builtin_amdgcn_sched_barrier(0); mm(3); __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: K-tile 0 whole, A0 and B0 of K-tile 1 — the state the stream is in at the start of every K-tile
+  issue(ic<0>{}, 0); issue(ic<1>{}, 0); issue(ic<3>{}, 0); issue(ic<2>{}, 0);
+  issue(ic<0>{}, 1); issue(ic<1>{}, 1);
+  pp_wait_vm<8>();                                // K-tile 0 has landed (my pieces)
+  pp_barrier();                                   // ... and everyone's
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { read_a1(0, ic<0>{}, ic<0>{}, a0, g); read_b1(0, ic<0>{}, ic<0>{}, b0, g); }
+
+  auto tile = [&](auto par_c, int t, auto f) {
+    phase(par_c, ic<0>{}, ic<0>{}, t, f); phase(par_c, ic<0>{}, ic<1>{}, t, f); phase(par_c, ic<0>{}, ic<2>{}, t, f); phase(par_c, ic<0>{}, ic<3>{}, t, f);
+    phase(par_c, ic<1>{}, ic<0>{}, t, f); phase(par_c, ic<1>{}, ic<1>{}, t, f); phase(par_c, ic<1>{}, ic<2>{}, t, f); phase(par_c, ic<1>{}, ic<3>{}, t, f);
+  };
+  tile(ic<0>{}, 0, std::true_type{});
+  for (int t = 1; t < n; t += 2) {
+    tile(ic<1>{}, t, std::false_type{});
+    if (t + 1 < n) tile(ic<0>{}, t + 1, std::false_type{});
+  }
+  pp_wait_vm<0>();                                // no DMA may land after the workgroup is gone
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto store_rows = [&](auto hm_c, auto hn_c, auto i_c) {
+    constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value, i = decltype(i_c)::value;
+    f32x4 row[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row[0][j] = acc_read(acc[hm][hn][i][j]);
+    write_acc_tiles<1, 4, true>(p, row, cb * 16 + hn * 8 + wc * 4, l15, quad, 0, mrow0 + hm * 128 + wr * 64 + i * 16);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_quadrant = [&](auto hm_c, auto hn_c) {
+    store_rows(hm_c, hn_c, ic<0>{}); store_rows(hm_c, hn_c, ic<1>{}); store_rows(hm_c, hn_c, ic<2>{}); store_rows(hm_c, hn_c, ic<3>{});
+  };
+  store_quadrant(ic<0>{}, ic<0>{}); store_quadrant(ic<0>{}, ic<1>{}); store_quadrant(ic<1>{}, ic<0>{}); store_quadrant(ic<1>{}, ic<1>{});
+}
+
 }  // namespace dlia
 
 using namespace dlia;
 
 // Which kernel serves bf16 GEMMs of more than 256 rows: 0 = this one (default), 2 = the 256 x 128
-// loader-wave kernel of gemm_rows.hip (also: DLIA_GEMM_LARGE=stream). which < 0 only reads.
+// loader-wave kernel of gemm_rows.hip (also: DLIA_GEMM_LARGE=stream), 4 = the four-wave kernel above for
+// launches that do not split K (DLIA_GEMM_LARGE=quad). which < 0 only reads.
 extern "C" int dlia_gemm_large_choice(int which) {
-  static std::atomic<int> v{[] { const char* e = getenv("DLIA_GEMM_LARGE"); return (e && e[0] == 's') ? 2 : 0; }()};
+  static std::atomic<int> v{[] { const char* e = getenv("DLIA_GEMM_LARGE"); return (e && e[0] == 's') ? 2 : ((e && e[0] == 'q') ? 4 : 0); }()};
   return which < 0 ? v.load() : v.exchange(which);
 }
 
@@ -453,8 +681,18 @@ static void launch_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
   const int nb = (p->ntiles + 15) / 16, nb8 = (nb + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
   hipLaunchKernelGGL((gemm_pingpong_kernel<F8, CMAX>), dim3(nb8 * mblocks * p->splitk), dim3(kPPThreads), kPPLds, stream, *p);
 }
+static void launch_quad(const dlia::GemmParams* p, hipStream_t stream) {
+  static const bool once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_quad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPPLds);
+    return true;
+  }();
+  (void)once;
+  const int nb = (p->ntiles + 15) / 16, nb8 = (nb + 7) / 8 * 8, mblocks = (p->M + 255) / 256;
+  hipLaunchKernelGGL(gemm_quad_kernel, dim3(nb8 * mblocks), dim3(kQThreads), kPPLds, stream, *p);
+}
 extern "C" void dlia_gemm_pingpong(const dlia::GemmParams* p, hipStream_t stream) {
   if (p->chunk_max != nullptr) launch_pingpong<false, true>(p, stream);
+  else if (dlia_gemm_large_choice(-1) == 4 && p->splitk == 1 && p->K >= 128) launch_quad(p, stream);
   else                         launch_pingpong<false>(p, stream);
 }
 
@@ -475,7 +713,7 @@ extern "C" void dlia_gemm_large(void* out, const void* x, const void* wp, const 
   p.ntiles = packed_ntiles(N);
   p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
   p.out_f32 = out_f32; p.partial_only = 0; p.splitk = 1; p.group_n = 1; p.counters = nullptr;
-  if (dlia_gemm_large_choice(-1) != 0 && chunk_max == nullptr) { dlia_gemm_rows(&p, stream); return; }
+  if (dlia_gemm_large_choice(-1) == 2 && chunk_max == nullptr) { dlia_gemm_rows(&p, stream); return; }
   const int s = pp_splitk(M, N, K / 64, wg_target);
   const long tiles = (long)((M + 255) / 256) * ((p.ntiles + 15) / 16);
   if (workspace && s > 1 && ws_floats >= tiles * (s - 1) * kPPSlab + kPPCounters) {
@@ -500,7 +738,7 @@ extern "C" void dlia_gemm_a8w8_large(void* out, const void* xq, const float* xsc
   p.ntiles = packed_ntiles(N);
   p.act = epi == 4 ? 1 : (epi == 5 ? 2 : 0);
   p.out_f32 = out_f32; p.partial_only = 0; p.splitk = 1; p.group_n = 1; p.counters = nullptr;
-  if (dlia_gemm_large_choice(-1) != 0) { p.partial = nullptr; dlia_gemm_rows_f8(&p, stream); return; }
+  if (dlia_gemm_large_choice(-1) == 2) { p.partial = nullptr; dlia_gemm_rows_f8(&p, stream); return; }
   const int s = pp_splitk(M, N, K / 128, wg_target);
   const long tiles = (long)((M + 255) / 256) * ((p.ntiles + 15) / 16);
   if (workspace && s > 1 && ws_floats >= tiles * (s - 1) * kPPSlab + kPPCounters) {

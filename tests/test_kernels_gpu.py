@@ -344,13 +344,13 @@ def test_gemm_a8w8_large_m_llama_shape(K):
     _gemm_a8w8_case(K, 512, 1152, 1024, 0, 1, out_f32=True)      # 72 n-tiles: 9 column blocks, grid padded to 16
 
 
-LARGE_KERNELS = {"pingpong": 0, "stream": 2}     # see the `large_gemm_kernel` op
+LARGE_KERNELS = {"pingpong": 0, "stream": 2, "quad": 6}     # see the `large_gemm_kernel` op
 
 
 @pytest.fixture(params=sorted(LARGE_KERNELS))
 def large_kernel(K, request):
-    """Each kernel for more than 256 rows in turn: the 256 x 256 ping-pong kernel (the default) and the
-    256 x 128 loader-wave kernel walking 256-row blocks."""
+    """Each kernel for more than 256 rows in turn: the 256 x 256 ping-pong kernel (the default), the
+    256 x 128 loader-wave kernel walking 256-row blocks, and the four-wave 256 x 256 kernel (launches that do not split K)."""
     prev = K.large_gemm_kernel(LARGE_KERNELS[request.param])
     yield request.param
     K.large_gemm_kernel(prev)
