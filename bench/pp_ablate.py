@@ -1,6 +1,7 @@
 """Ablation timing of the 256 x 256 ping-pong GEMM: diagnostic builds of gemm_pingpong.hip with parts
 of the main loop left out (PP_ABL mask: 1 DMA issue, 2 fragment reads, 4 barriers, 8 MFMAs; for the four-wave
-kernel, selected with DLIA_GEMM_LARGE=quad: 64 landing waits, 128 barriers, 256 DMA issue), timed on
+kernel, selected with DLIA_GEMM_LARGE=quad: 64 landing waits, 128 barriers, 256 DMA issue, 512 all but one row of the
+epilogue), timed on
 the Llama-3-8B layer shapes. The outputs of an ablated build are wrong on purpose; the times say what
 the remaining parts cost. Build on the CPU box first (`--build`), run on the GPU.
 
@@ -72,7 +73,7 @@ def main():
             # whatever the register holds, and a stray `chunk_max` pointer is written through
             f.argtypes = [vp, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
                           C.c_int, C.c_int, C.c_int, vp, vp, C.c_long, C.c_int]
-            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile"), (32, "stamps"), (64, "q:noWAIT"), (128, "q:noBAR"), (256, "q:noDMA")) if mask & b) + ")"]
+            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile"), (32, "stamps"), (64, "q:noWAIT"), (128, "q:noBAR"), (256, "q:noDMA"), (512, "q:noEPILOGUE")) if mask & b) + ")"]
             tt, tf = 0.0, 0.0
             for name, N, K in shapes:
                 x, wp, out = data[name]

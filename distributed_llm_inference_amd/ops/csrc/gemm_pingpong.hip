@@ -616,6 +616,9 @@ __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
   __builtin_amdgcn_sched_barrier(0);
 
+  // One quadrant at a time: its 16 tiles are copied out (64 registers) and stored together, so that the conversions and
+  // stores of a whole quadrant overlap; tile row by tile row the lone wave of a SIMD waited on every store's address
+  // arithmetic and the epilogue took three times as long as the eight-wave kernel's.
   auto store_rows = [&](auto hm_c, auto hn_c, auto i_c) {
     constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value, i = decltype(i_c)::value;
     f32x4 row[1][4];
@@ -625,8 +628,19 @@ __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
   auto store_quadrant = [&](auto hm_c, auto hn_c) {
-    store_rows(hm_c, hn_c, ic<0>{}); store_rows(hm_c, hn_c, ic<1>{}); store_rows(hm_c, hn_c, ic<2>{}); store_rows(hm_c, hn_c, ic<3>{});
+    constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value;
+    f32x4 tiles[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tiles[i][j] = acc_read(acc[hm][hn][i][j]);
+    write_acc_tiles<4, 4, true>(p, tiles, cb * 16 + hn * 8 + wc * 4, l15, quad, 0, mrow0 + hm * 128 + wr * 64);
+    __builtin_amdgcn_sched_barrier(0);
   };
+  if constexpr (PP_ABL & 512) {                   // diagnostic: one row of tiles only (what the rest of the epilogue costs)
+    store_rows(ic<0>{}, ic<0>{}, ic<0>{});
+    return;
+  }
   store_quadrant(ic<0>{}, ic<0>{}); store_quadrant(ic<0>{}, ic<1>{}); store_quadrant(ic<1>{}, ic<0>{}); store_quadrant(ic<1>{}, ic<1>{});
 }
 
