@@ -1,5 +1,5 @@
 """Ablation timing of the 256 x 256 ping-pong GEMM: diagnostic builds of gemm_pingpong.hip with parts
-of the main loop left out (PP_ABL mask: 1 DMA issue, 2 fragment reads, 4 barriers, 8 MFMAs; for the four-wave
+of the main loop left out (PP_ABL mask: 1 DMA issue, 2 fragment reads, 4 barriers, 8 MFMAs, 2048 three quarters of the epilogue; for the four-wave
 kernel, selected with DLIA_GEMM_LARGE=quad: 64 landing waits, 128 barriers, 256 DMA issue, 512 all but one row of the
 epilogue), timed on
 the Llama-3-8B layer shapes. The outputs of an ablated build are wrong on purpose; the times say what
@@ -73,13 +73,13 @@ def main():
             # whatever the register holds, and a stray `chunk_max` pointer is written through
             f.argtypes = [vp, vp, vp, vp, vp, vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long,
                           C.c_int, C.c_int, C.c_int, vp, vp, C.c_long, C.c_int]
-            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile"), (32, "stamps"), (64, "q:noWAIT"), (128, "q:noBAR"), (256, "q:noDMA"), (512, "q:noEPILOGUE")) if mask & b) + ")"]
+            line = [f"M={M} pad={pad} mask={mask:2d} (" + "+".join(n for b, n in ((1, "noDMA"), (2, "noREAD"), (4, "noBAR"), (8, "noMFMA"), (16, "sameTile"), (32, "stamps"), (64, "q:noWAIT"), (128, "q:noBAR"), (256, "q:noDMA"), (512, "q:noEPILOGUE"), (1024, "q:stamps"), (2048, "quarterEPILOGUE")) if mask & b) + ")"]
             tt, tf = 0.0, 0.0
             for name, N, K in shapes:
                 x, wp, out = data[name]
                 st = torch.cuda.current_stream().cuda_stream
 
-                stamps = torch.zeros(((M + 255) // 256) * ((N + 2047) // 2048 * 8) * 8 * 16 + 64, device="cuda", dtype=torch.int32) if mask & 32 else None
+                stamps = torch.zeros(((M + 255) // 256) * ((N + 2047) // 2048 * 8) * 8 * 16 + 64, device="cuda", dtype=torch.int32) if mask & (32 | 1024) else None
 
                 def run():
                     f(out.data_ptr(), x.data_ptr(), wp.data_ptr(), None, None, stamps.data_ptr() if stamps is not None else None,
@@ -96,7 +96,13 @@ def main():
                 fl = 2.0 * M * N * K
                 tt += t; tf += fl
                 line.append(f"{name} {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}T")
-                if stamps is not None:
+                if stamps is not None and mask & 1024:
+                    v = stamps[:-64].view(-1, 8, 16)[:, :4, :4].float()
+                    v = v[v[:, 0, 3] > 0]                           # workgroups that ran
+                    c = v.mean(dim=(0, 1))                          # 100 MHz ticks
+                    print(f"    {name}: per workgroup, us: prologue {c[0].item() / 100:.2f}  K loop {c[1].item() / 100:.2f}  "
+                          f"tail + epilogue {c[2].item() / 100:.2f}  ({v.shape[0]} workgroups, {K // 64} K-tiles)", flush=True)
+                elif stamps is not None:
                     v = stamps[:-64].view(-1, 8, 4, 4).float()
                     v = v[v.sum(dim=(1, 2, 3)) > 0]                 # workgroups that ran (the grid is padded)
                     ktiles = K // 64

@@ -40,7 +40,9 @@ __device__ __forceinline__ void store4(void* out, long ldo, int m, int n, const 
 
 // Shared by the direct epilogue and the split-K reduce kernel: v = 4 consecutive columns
 // n..n+3 of row m (for swiglu: g = gate values, u = up values of output columns n..n+3).
-__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, float (&g)[4], const float (&u)[4]) {
+// `res`: the residual's four values when the caller has loaded them already (null: loaded here).
+__device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, float (&g)[4], const float (&u)[4],
+                                          const u32x2* res = nullptr) {
   if (p.bias) {
     const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
     g[0] += bf16_lo(b[0]); g[1] += bf16_hi(b[0]); g[2] += bf16_lo(b[1]); g[3] += bf16_hi(b[1]);
@@ -53,7 +55,7 @@ __device__ __forceinline__ void epilogue4(const GemmParams& p, int m, int n, flo
     for (int r = 0; r < 4; ++r) g[r] = gelu_tanh(g[r]);
   }
   if (p.residual) {
-    const u32x2 b = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
+    const u32x2 b = res ? *res : *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
     g[0] += bf16_lo(b[0]); g[1] += bf16_hi(b[0]); g[2] += bf16_lo(b[1]); g[3] += bf16_hi(b[1]);
   }
   store4(p.out, p.ldo, m, n, g, p.out_f32);
@@ -79,6 +81,18 @@ __device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc
     }
     return;
   }
+  // The residual of every tile of the call first (the tiled kernels' O and down projections): one load per tile
+  // issued and waited for in turn left a wave idle for a memory latency per tile.
+  u32x2 rres[MT][NTW];
+  if (DIRECT && p.residual && p.act != 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int m = min(m0 + i * 16 + l15, p.M - 1), n = min((tile0 + j) * 16 + quad * 4, p.N - 4);
+        rres[i][j] = *reinterpret_cast<const u32x2*>(p.residual + (long)m * p.ldr + n);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + i * 16 + l15;
@@ -102,7 +116,7 @@ __device__ __forceinline__ void write_acc_tiles(const GemmParams& p, f32x4 (&acc
         const int n = (tile0 + j) * 16 + quad * 4;
         if (n < p.N) {
           float g[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          epilogue4(p, m, n, g, g);
+          epilogue4(p, m, n, g, g, DIRECT ? &rres[i][j] : nullptr);
         }
       }
     }

@@ -396,6 +396,10 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
         }
       }
   }
+  if constexpr (PP_ABL & 2048) {                  // diagnostic: one quadrant of the epilogue only
+    write_acc_tiles<4, 2, true>(p, acc[0][0], cb * 16 + wc * 2, l15, quad, 0, mrow0 + wr * 64);
+    return;
+  }
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
@@ -471,6 +475,8 @@ __device__ __forceinline__ f32x4 acc_read(f32x4 c) {
 
 __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;     // diagnostic (PP_ABL & 1024): kernel start, first MFMA, end of the K loop
+  if constexpr (PP_ABL & 1024) st0 = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, quad = lane >> 4;
@@ -607,11 +613,13 @@ __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
     phase(par_c, ic<0>{}, ic<0>{}, t, f); phase(par_c, ic<0>{}, ic<1>{}, t, f); phase(par_c, ic<0>{}, ic<2>{}, t, f); phase(par_c, ic<0>{}, ic<3>{}, t, f);
     phase(par_c, ic<1>{}, ic<0>{}, t, f); phase(par_c, ic<1>{}, ic<1>{}, t, f); phase(par_c, ic<1>{}, ic<2>{}, t, f); phase(par_c, ic<1>{}, ic<3>{}, t, f);
   };
+  if constexpr (PP_ABL & 1024) st1 = __builtin_amdgcn_s_memtime();
   tile(ic<0>{}, 0, std::true_type{});
   for (int t = 1; t < n; t += 2) {
     tile(ic<1>{}, t, std::false_type{});
     if (t + 1 < n) tile(ic<0>{}, t + 1, std::false_type{});
   }
+  if constexpr (PP_ABL & 1024) st2 = __builtin_amdgcn_s_memtime();
   pp_wait_vm<0>();                                // no DMA may land after the workgroup is gone
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
   __builtin_amdgcn_sched_barrier(0);
@@ -642,6 +650,14 @@ __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
     return;
   }
   store_quadrant(ic<0>{}, ic<0>{}); store_quadrant(ic<0>{}, ic<1>{}); store_quadrant(ic<1>{}, ic<0>{}); store_quadrant(ic<1>{}, ic<1>{});
+  if constexpr (PP_ABL & 1024) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && p.partial != nullptr) {       // (bench/pp_ablate.py passes a stamp buffer as the workspace)
+      unsigned* o = reinterpret_cast<unsigned*>(p.partial) + ((long)blockIdx.x * 8 + wave) * 16;
+      o[0] = (unsigned)(st1 - st0); o[1] = (unsigned)(st2 - st1); o[2] = (unsigned)(st3 - st2); o[3] = 1u;
+    }
+  }
 }
 
 }  // namespace dlia

@@ -75,10 +75,21 @@ void* dlia_board_open(const char* name, int create, uint32_t num_stages, int tim
   h->bytes = sizeof(Board);
   strncpy(h->name, name, sizeof(h->name) - 1);
   if (create) {
-    memset(p, 0, sizeof(Board));
+    // (the fresh segment is zero-filled by ftruncate; clearing it here again would wipe a registration that an
+    // attaching stage made between the two)
     h->b->num_stages = num_stages;
     std::atomic_thread_fence(std::memory_order_release);
     h->b->magic = kMagic;
+  } else {
+    // The segment has its size before it has its contents: wait until the creator has published the header. Without
+    // this a stage attaching in that window read 0 stages and "agreed" on the KV blocks of an empty list.
+    auto t0 = std::chrono::steady_clock::now();
+    while (reinterpret_cast<volatile uint32_t&>(h->b->magic) != kMagic) {
+      auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > timeout_ms) { munmap(p, sizeof(Board)); delete h; return nullptr; }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
   }
   return h;
 }

@@ -101,7 +101,7 @@ class StatusBoard:
             vals = [self.read(s) for s in range(self.num_stages)]
             if any(v["state"] == "error" for v in vals):
                 raise RuntimeError("a stage failed during bring-up: " + "; ".join(v["error"] for v in vals if v["error"]))
-            if all(v["kv_blocks"] > 0 for v in vals):
+            if vals and all(v["kv_blocks"] > 0 for v in vals):
                 return min(v["kv_blocks"] for v in vals)
             if time.time() - t0 > timeout_s:
                 raise TimeoutError("stages did not agree on a KV block count")

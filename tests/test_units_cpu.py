@@ -504,3 +504,42 @@ def test_hardware_queue_rule(monkeypatch):
     assert after(GPU_MAX_HW_QUEUES="4", WORLD_SIZE="8", DLIA_SHARE_GPU="1") == "4"
     assert after(GPU_MAX_HW_QUEUES="4", WORLD_SIZE="8", DLIA_KEEP_HW_QUEUES="1") == "4"
     assert after(GPU_MAX_HW_QUEUES="x", WORLD_SIZE="8") == "8"                   # an unreadable value counts as unset
+
+
+def test_a_stage_attaching_to_the_status_board_waits_for_its_header():
+    """The shared-memory segment has its size before it has its contents: a stage that attaches in that window
+    must wait for the creator's header instead of reading a board of 0 stages (on which `agree_kv_blocks` then
+    "agreed" over an empty list — seen once with four ranks coming up together)."""
+    import mmap
+    import struct
+    import threading
+    import time
+    from distributed_llm_inference_amd.parallel.shm import StatusBoard
+    name = f"dlia_test_board_{os.getpid()}"
+    path = "/dev/shm/" + name
+    with open(path, "wb") as f:
+        f.truncate(1 << 20)                      # sized, still all zeros: no magic, no stage count
+    got = {}
+
+    def attach():
+        b = StatusBoard(name, create=False, timeout_s=10.0)
+        got["stages"], got["t"] = b.num_stages, time.time()
+        b._owner = False
+        b.close()
+
+    try:
+        th = threading.Thread(target=attach)
+        t0 = time.time()
+        th.start()
+        time.sleep(0.3)
+        assert "stages" not in got               # still waiting
+        with open(path, "r+b") as f:
+            m = mmap.mmap(f.fileno(), 4096)
+            m[4:8] = struct.pack("<I", 3)        # num_stages first, the magic word last
+            m[0:4] = struct.pack("<I", 0x424F5244)
+            m.flush()
+            m.close()
+        th.join(10)
+        assert got.get("stages") == 3 and got["t"] - t0 >= 0.3
+    finally:
+        os.unlink(path)
