@@ -129,7 +129,8 @@ def main(argv=None) -> int:
         spec = resolve_spec(cfg)
         for pl in plans_for(cfg, spec):
             extra = [x for x, on in (("embedding", pl.has_embed), ("final norm + lm_head + sampler", pl.has_head)) if on]
-            print(f"stage {pl.stage}: layers [{pl.layer_start}, {pl.layer_end})" + (f" + {', '.join(extra)}" if extra else ""))
+            # x.5 = a boundary between a layer's attention and MLP blocks (`StagePlan.describe`)
+            print(f"stage {pl.stage}: layers {pl.describe()}" + (f" + {', '.join(extra)}" if extra else ""))
     elif a.cmd == "bench":
         import os
         import runpy

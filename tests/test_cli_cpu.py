@@ -44,11 +44,11 @@ def test_config_precedence_yaml_env_flags(tmp_path, monkeypatch):
 def test_plan_command_prints_the_reference_split(capsys):
     assert cli.main(["plan", "--model", "tinyllama-1.1b", "--pp-size", "2", "--partition", "even"]) == 0
     out = capsys.readouterr().out
-    assert "stage 0: layers [0, 11) + embedding" in out          # Worker1.py:27-28
-    assert "stage 1: layers [11, 22) + final norm + lm_head + sampler" in out   # Worker2.py:26-27
+    assert "stage 0: layers 0-11 + embedding" in out          # Worker1.py:27-28
+    assert "stage 1: layers 11-22 + final norm + lm_head + sampler" in out   # Worker2.py:26-27
     cli.main(["plan", "--model", "llama-3-70b", "--pp-size", "8"])
     lines = capsys.readouterr().out.strip().splitlines()
-    assert len(lines) == 8 and lines[-1].startswith("stage 7: layers [")
+    assert len(lines) == 8 and lines[-1].startswith("stage 7: layers ")
 
 
 def test_generate_command(capsys):
