@@ -97,11 +97,12 @@ def main():
                 tt += t; tf += fl
                 line.append(f"{name} {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}T")
                 if stamps is not None and mask & 1024:
-                    v = stamps[:-64].view(-1, 8, 16)[:, :4, :4].float()
+                    v = stamps[:-64].view(-1, 8, 16)[:, :4, :8].float()
                     v = v[v[:, 0, 3] > 0]                           # workgroups that ran
-                    c = v.mean(dim=(0, 1))                          # 100 MHz ticks
-                    print(f"    {name}: per workgroup, us: prologue {c[0].item() / 100:.2f}  K loop {c[1].item() / 100:.2f}  "
-                          f"tail + epilogue {c[2].item() / 100:.2f}  ({v.shape[0]} workgroups, {K // 64} K-tiles)", flush=True)
+                    c = v.mean(dim=(0, 1))                          # s_memtime ticks
+                    print(f"    {name}: per workgroup, ticks: prologue {c[0].item():.0f}  K loop {c[1].item():.0f}  "
+                          f"tail + epilogue {c[2].item():.0f} = DMA tail + barrier {c[4].item():.0f} + tiles {c[5].item():.0f} + "
+                          f"store drain {c[6].item():.0f}  ({v.shape[0]} workgroups, {K // 64} K-tiles)", flush=True)
                 elif stamps is not None:
                     v = stamps[:-64].view(-1, 8, 4, 4).float()
                     v = v[v.sum(dim=(1, 2, 3)) > 0]                 # workgroups that ran (the grid is padded)

@@ -624,25 +624,123 @@ __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
   __builtin_amdgcn_sched_barrier(0);
 
-  // One quadrant at a time: its 16 tiles are copied out (64 registers) and stored together, so that the conversions and
-  // stores of a whole quadrant overlap; tile row by tile row the lone wave of a SIMD waited on every store's address
-  // arithmetic and the epilogue took three times as long as the eight-wave kernel's.
-  auto store_rows = [&](auto hm_c, auto hn_c, auto i_c) {
+  // Epilogue through LDS, as a LOOP over tiles: a wave's 64 tiles unrolled through the general epilogue are ~9,400
+  // instructions of straight-line code that every workgroup runs once — instruction fetch, not arithmetic or stores,
+  // made that epilogue take ~19 us per workgroup (three times the eight-wave kernel's, whose waves run half as much
+  // code each). Per quadrant a wave parks its 16 tiles in its own 16 KiB of the (now idle) staging area, lane-linear,
+  // and a rolled loop reads one tile (or a gate / up pair) back and finishes it: the epilogue's code exists once.
+  pp_barrier();                                   // every wave has read its last fragments: the staging area is free
+  unsigned long long st2b = 0;
+  if constexpr (PP_ABL & 1024) st2b = __builtin_amdgcn_s_memtime();
+  char* const stage = smem + wave * 17408 + lane * 16;      // (each wave has 17408 bytes: the row-wise fast paths pad their rows)
+  auto store_rows = [&](auto hm_c, auto hn_c, auto i_c) {       // (diagnostic builds only: one row of tiles)
     constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value, i = decltype(i_c)::value;
     f32x4 row[1][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) row[0][j] = acc_read(acc[hm][hn][i][j]);
     write_acc_tiles<1, 4, true>(p, row, cb * 16 + hn * 8 + wc * 4, l15, quad, 0, mrow0 + hm * 128 + wr * 64 + i * 16);
-    __builtin_amdgcn_sched_barrier(0);
   };
-  auto store_quadrant = [&](auto hm_c, auto hn_c) {
+  // Fast paths for what a Llama layer asks of this kernel — bf16 out, no bias, whole quadrant inside N: plain or
+  // + residual (QKV, O, down) and SwiGLU (gate / up). In the accumulator layout a lane holds 4 columns of one row of a
+  // tile, so a store instruction writes 8 bytes per lane into 16 different rows (32-byte pieces of 16 cache lines), and
+  // 64 of those per wave, ~250 cycles apart, were the 16-20 thousand cycles a workgroup spent after its last MFMA. The
+  // quadrant goes through the wave's own LDS area instead (fp32, rows padded to 272 / 144 bytes) and comes back row-wise:
+  // 16 bytes per lane, 8 (16) whole rows of 128 (64) contiguous bytes per store, the residual read the same way.
+  constexpr int kRowF = 68, kRowH = 36;           // floats per staged row: 64 (32) + 4 of padding
+  float* const stq = reinterpret_cast<float*>(smem + wave * 17408);
+  auto fast_plain = [&](auto hm_c, auto hn_c, auto res_c) __attribute__((always_inline)) {
     constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value;
-    f32x4 tiles[4][4];
+    constexpr bool RES = decltype(res_c)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tiles[i][j] = acc_read(acc[hm][hn][i][j]);
-    write_acc_tiles<4, 4, true>(p, tiles, cb * 16 + hn * 8 + wc * 4, l15, quad, 0, mrow0 + hm * 128 + wr * 64);
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(stq + (i * 16 + l15) * kRowF + j * 16 + quad * 4) = acc_read(acc[hm][hn][i][j]);
+    const int col0 = (cb * 16 + hn * 8 + wc * 4) * 16 + (lane & 7) * 8;
+    const int row0 = mrow0 + hm * 128 + wr * 64 + (lane >> 3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int m = row0 + k * 8, mc = min(m, p.M - 1);
+      const float* src = stq + (k * 8 + (lane >> 3)) * kRowF + (lane & 7) * 8;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if constexpr (RES) {
+        float r[8];
+        unpack8(ld16(p.residual + (long)mc * p.ldr + col0), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (m < p.M) st16(reinterpret_cast<bf16*>(p.out) + (long)mc * p.ldo + col0, pack8(v));
+    }
+  };
+  auto fast_swiglu = [&](auto hm_c, auto hn_c) __attribute__((always_inline)) {
+    constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {            // (gate tile, up tile) -> one output tile
+        const f32x4 g = acc_read(acc[hm][hn][i][2 * jp]), u = acc_read(acc[hm][hn][i][2 * jp + 1]);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = silu(g[e]) * u[e];
+        *reinterpret_cast<f32x4*>(stq + (i * 16 + l15) * kRowH + jp * 16 + quad * 4) = o;
+      }
+    const int col0 = ((cb * 16 + hn * 8 + wc * 4) >> 1) * 16 + (lane & 3) * 8;
+    const int row0 = mrow0 + hm * 128 + wr * 64 + (lane >> 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int m = row0 + k * 16;
+      const float* src = stq + (k * 16 + (lane >> 2)) * kRowH + (lane & 3) * 8;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (m < p.M) st16(reinterpret_cast<bf16*>(p.out) + (long)m * p.ldo + col0, pack8(v));
+    }
+  };
+  auto store_quadrant = [&](auto hm_c, auto hn_c) __attribute__((always_inline)) {
+    constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value;
+    const int tile_base = cb * 16 + hn * 8 + wc * 4, row_base = mrow0 + hm * 128 + wr * 64 + l15;
+    if (!p.out_f32 && p.bias == nullptr && (PP_ABL & 4096) == 0) {
+      if (p.act == 0 && (tile_base + 4) * 16 <= p.N) {
+        if (p.residual) fast_plain(hm_c, hn_c, std::true_type{});
+        else            fast_plain(hm_c, hn_c, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+      }
+      if (p.act == 1 && p.residual == nullptr && ((tile_base >> 1) + 2) * 16 <= (p.N >> 1)) {
+        fast_swiglu(hm_c, hn_c);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(stage + (i * 4 + j) * 1024) = acc_read(acc[hm][hn][i][j]);
+    if (p.act == 1) {
+#pragma unroll 2
+      for (int t = 0; t < 8; ++t) {               // (gate tile, up tile) pairs
+        const int i = t >> 1, j = (t & 1) * 2;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(stage + (i * 4 + j) * 1024);
+        const f32x4 uv = *reinterpret_cast<const f32x4*>(stage + (i * 4 + j + 1) * 1024);
+        const int m = row_base + i * 16, n = ((tile_base + j) >> 1) * 16 + quad * 4;
+        if (m < p.M && n < (p.N >> 1)) {
+          float g[4] = {gv[0], gv[1], gv[2], gv[3]};
+          const float u[4] = {uv[0], uv[1], uv[2], uv[3]};
+          epilogue4(p, m, n, g, u);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int t = 0; t < 16; ++t) {
+        const int i = t >> 2, j = t & 3;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(stage + t * 1024);
+        const int m = row_base + i * 16, n = (tile_base + j) * 16 + quad * 4;
+        if (m < p.M && n < p.N) {
+          float g[4] = {gv[0], gv[1], gv[2], gv[3]};
+          epilogue4(p, m, n, g, g);
+        }
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
   if constexpr (PP_ABL & 512) {                   // diagnostic: one row of tiles only (what the rest of the epilogue costs)
@@ -651,11 +749,13 @@ __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
   }
   store_quadrant(ic<0>{}, ic<0>{}); store_quadrant(ic<0>{}, ic<1>{}); store_quadrant(ic<1>{}, ic<0>{}); store_quadrant(ic<1>{}, ic<1>{});
   if constexpr (PP_ABL & 1024) {
+    const unsigned long long st3a = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st3 = __builtin_amdgcn_s_memtime();
     if (lane == 0 && p.partial != nullptr) {       // (bench/pp_ablate.py passes a stamp buffer as the workspace)
       unsigned* o = reinterpret_cast<unsigned*>(p.partial) + ((long)blockIdx.x * 8 + wave) * 16;
       o[0] = (unsigned)(st1 - st0); o[1] = (unsigned)(st2 - st1); o[2] = (unsigned)(st3 - st2); o[3] = 1u;
+      o[4] = (unsigned)(st2b - st2); o[5] = (unsigned)(st3a - st2b); o[6] = (unsigned)(st3 - st3a);
     }
   }
 }
