@@ -396,6 +396,85 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
         }
       }
   }
+  // ---- row-wise epilogue for what a Llama layer asks of this kernel ------------------------------------
+  // bf16 out, no bias, the whole 256-column block inside N: plain or + residual (QKV, O, down) and SwiGLU (gate / up).
+  // In the accumulator layout a lane holds 4 columns of one row of a tile: a store writes 8 bytes per lane into 16
+  // different rows, 32 of those per wave (and as many residual loads). Here the block goes through the idle staging
+  // area as fp32 — 16-byte slots XOR-ed with the row's low four bits, so the 16 rows a write instruction touches fall
+  // on different banks — and every wave stores whole rows: 16 bytes per lane, two rows of 512 contiguous bytes (four
+  // of 256 for SwiGLU) per instruction, the residual read the same way. Plain: one row half (128 x 256 fp32 = the
+  // whole 128 KiB) at a time; SwiGLU: gate and up meet in registers, the 256 x 128 results are staged at once.
+  if (!p.out_f32 && p.bias == nullptr && (cb + 1) * 256 <= p.N && (PP_ABL & 4096) == 0 &&
+      (p.act == 0 || (p.act == 1 && p.residual == nullptr)) &&
+      ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.residual)) & 15) == 0 && ((p.ldo | p.ldr) & 7) == 0) {
+    float* const st = reinterpret_cast<float*>(smem);
+    if (p.act == 0) {
+      const int cl = lane & 31, rsub = lane >> 5;
+      bf16* const outp = reinterpret_cast<bf16*>(p.out) + cb * 256 + cl * 8;
+      const bf16* const resp = p.residual + cb * 256 + cl * 8;     // (only dereferenced when there is a residual)
+#pragma unroll
+      for (int hm = 0; hm < 2; ++hm) {
+        pp_barrier();                             // the area is free: all DMA landed and fragments read / previous half read back
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              *reinterpret_cast<f32x4*>(st + (wr * 64 + i * 16 + l15) * 256 + (((hn * 32 + wc * 8 + j * 4 + quad) ^ l15) << 2)) =
+                  acc[hm][hn][i][j];
+        const int m0 = mrow0 + hm * 128 + wave * 16 + rsub;
+        u32x4 res[8];
+        if (p.residual) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) res[s] = ld16(resp + (long)min(m0 + 2 * s, p.M - 1) * p.ldr);
+        }
+        pp_barrier();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int R = wave * 16 + s * 2 + rsub;
+          const float* row = st + R * 256;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * cl) ^ (R & 15)) << 2));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * cl + 1) ^ (R & 15)) << 2));
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (p.residual) {
+            float r8[8];
+            unpack8(res[s], r8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r8[e];
+          }
+          if (m0 + 2 * s < p.M) st16(outp + (long)(m0 + 2 * s) * p.ldo, pack8(v));
+        }
+      }
+    } else {
+      pp_barrier();
+#pragma unroll
+      for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = silu(acc[hm][hn][i][0][e]) * acc[hm][hn][i][1][e];
+            *reinterpret_cast<f32x4*>(st + (hm * 128 + wr * 64 + i * 16 + l15) * 128 + (((hn * 16 + wc * 4 + quad) ^ l15) << 2)) = o;
+          }
+      const int cl = lane & 15, rsub = lane >> 4;
+      bf16* const outp = reinterpret_cast<bf16*>(p.out) + cb * 128 + cl * 8;
+      const int m0 = mrow0 + wave * 32 + rsub;
+      pp_barrier();
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int R = wave * 32 + s * 4 + rsub;
+        const float* row = st + R * 128;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * cl) ^ (R & 15)) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * cl + 1) ^ (R & 15)) << 2));
+        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (m0 + 4 * s < p.M) st16(outp + (long)(m0 + 4 * s) * p.ldo, pack8(v));
+      }
+    }
+    return;
+  }
   if constexpr (PP_ABL & 2048) {                  // diagnostic: one quadrant of the epilogue only
     write_acc_tiles<4, 2, true>(p, acc[0][0], cb * 16 + wc * 2, l15, quad, 0, mrow0 + wr * 64);
     return;
@@ -699,7 +778,8 @@ __global__ __launch_bounds__(kQThreads, 1) void gemm_quad_kernel(GemmParams p) {
   auto store_quadrant = [&](auto hm_c, auto hn_c) __attribute__((always_inline)) {
     constexpr int hm = decltype(hm_c)::value, hn = decltype(hn_c)::value;
     const int tile_base = cb * 16 + hn * 8 + wc * 4, row_base = mrow0 + hm * 128 + wr * 64 + l15;
-    if (!p.out_f32 && p.bias == nullptr && (PP_ABL & 4096) == 0) {
+    if (!p.out_f32 && p.bias == nullptr && (PP_ABL & 4096) == 0 && ((p.ldo | p.ldr) & 7) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.residual)) & 15) == 0) {
       if (p.act == 0 && (tile_base + 4) * 16 <= p.N) {
         if (p.residual) fast_plain(hm_c, hn_c, std::true_type{});
         else            fast_plain(hm_c, hn_c, std::false_type{});
