@@ -381,6 +381,31 @@ def test_gemm_pingpong_shapes(K, shape):
         K.large_gemm_kernel(prev)
 
 
+@pytest.mark.parametrize("epi", [0, 2, 4])
+@pytest.mark.parametrize("pad", [4, 8])
+def test_gemm_large_m_output_rows_that_are_not_16_byte_multiples(K, large_kernel, epi, pad):
+    """The row-wise epilogues of the large-M kernels store 16 bytes per lane: an output whose row stride
+    is 8 bytes off that (pad 4) must take the general epilogue, one that is a 16-byte multiple but not dense (pad 8)
+    the row-wise one with its stride; columns outside the output stay untouched either way."""
+    torch.manual_seed(3)
+    M, N, Kd = 520, 1024, 512
+    n_out = N // 2 if epi == 4 else N
+    x = bf(torch.randn(M, Kd, device=DEV))
+    if epi == 4:
+        wg, wu = (bf(torch.randn(n_out, Kd, device=DEV) / math.sqrt(Kd)) for _ in range(2))
+        wp, w_ref = packing.pack_weight(packing.interleave_gate_up(wg, wu)), torch.cat([wg, wu], 0)
+    else:
+        w_ref = bf(torch.randn(N, Kd, device=DEV) / math.sqrt(Kd))
+        wp = packing.pack_weight(w_ref)
+    res_big = bf(torch.randn(M, n_out + 8, device=DEV))      # (residual rows must be 16-byte multiples)
+    out_big = torch.full((M, n_out + pad), 7.0, device=DEV, dtype=torch.bfloat16)
+    res, out = res_big[:, :n_out], out_big[:, :n_out]
+    K.gemm(out, x, wp, None, res if epi == 2 else None, None, N, epi, 1, 0)
+    want = ref.gemm(x, w_ref, None, res if epi == 2 else None, epi)
+    assert_close(out, want, 3e-2, 2e-2, f"strided output epi={epi} pad={pad}")
+    assert bool((out_big[:, n_out:] == 7.0).all()), "columns past the output were written"
+
+
 @pytest.mark.parametrize("shape", [(1024, 4096, 4096, 2), (512, 6144, 4096, 0), (1024, 4096, 14336, 2), (512, 4096, 4096, 3),
                                    (700, 1152, 2048, 4), (300, 384, 1024, 5)])
 def test_gemm_pingpong_split_k_inside_the_launch(K, shape):
