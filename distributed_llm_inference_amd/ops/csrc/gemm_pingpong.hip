@@ -397,19 +397,21 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
       }
   }
   // ---- row-wise epilogue for what a Llama layer asks of this kernel ------------------------------------
-  // bf16 out, no bias, the whole 256-column block inside N: plain or + residual (QKV, O, down) and SwiGLU (gate / up).
+  // bf16 out, the whole 256-column block inside N: plain (+ bias, GELU, + residual: QKV, O, down, GPT-2's MLP) and SwiGLU (gate / up).
   // In the accumulator layout a lane holds 4 columns of one row of a tile: a store writes 8 bytes per lane into 16
   // different rows, 32 of those per wave (and as many residual loads). Here the block goes through the idle staging
   // area as fp32 — 16-byte slots XOR-ed with the row's low four bits, so the 16 rows a write instruction touches fall
   // on different banks — and every wave stores whole rows: 16 bytes per lane, two rows of 512 contiguous bytes (four
   // of 256 for SwiGLU) per instruction, the residual read the same way. Plain: one row half (128 x 256 fp32 = the
   // whole 128 KiB) at a time; SwiGLU: gate and up meet in registers, the 256 x 128 results are staged at once.
-  if (!p.out_f32 && p.bias == nullptr && (cb + 1) * 256 <= p.N && (PP_ABL & 4096) == 0 &&
-      (p.act == 0 || (p.act == 1 && p.residual == nullptr)) &&
-      ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.residual)) & 15) == 0 && ((p.ldo | p.ldr) & 7) == 0) {
+  if (!p.out_f32 && (cb + 1) * 256 <= p.N && (PP_ABL & 4096) == 0 &&
+      (p.act != 1 || (p.residual == nullptr && p.bias == nullptr)) && ((p.ldo | p.ldr) & 7) == 0 &&
+      ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0) {
     float* const st = reinterpret_cast<float*>(smem);
-    if (p.act == 0) {
+    if (p.act != 1) {
       const int cl = lane & 31, rsub = lane >> 5;
+      float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p.bias) unpack8(ld16(p.bias + cb * 256 + cl * 8), b8);
       bf16* const outp = reinterpret_cast<bf16*>(p.out) + cb * 256 + cl * 8;
       const bf16* const resp = p.residual + cb * 256 + cl * 8;     // (only dereferenced when there is a residual)
 #pragma unroll
@@ -437,6 +439,14 @@ __global__ __launch_bounds__(kPPThreads, 2) void gemm_pingpong_kernel(GemmParams
           const f32x4 lo = *reinterpret_cast<const f32x4*>(row + (((2 * cl) ^ (R & 15)) << 2));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(row + (((2 * cl + 1) ^ (R & 15)) << 2));
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b8[e];
+          }
+          if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+          }
           if (p.residual) {
             float r8[8];
             unpack8(res[s], r8);
