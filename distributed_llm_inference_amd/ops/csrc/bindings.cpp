@@ -5,6 +5,7 @@
 // through torch.cuda.graph().
 #include <torch/library.h>
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/util/Optional.h>
 
@@ -22,6 +23,11 @@ using OptTensor = const std::optional<Tensor>&;
 inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 
 #define DLIA_CHECK(cond, ...) TORCH_CHECK(cond, "dlia: ", __VA_ARGS__)
+// HIP's current device (and with it PyTorch's current stream) is per THREAD: a helper thread of a rank that serves
+// cuda:3 starts on device 0. Every op therefore runs on the device of its output tensor, whatever the calling thread's is.
+#define DLIA_ON_DEVICE_OF(t) \
+  DLIA_CHECK((t).is_cuda(), #t " must be a GPU tensor"); \
+  const c10::hip::HIPGuardMasqueradingAsCUDA dlia_device_guard_((t).device())
 
 inline void check_dev(const Tensor& t, const char* name) {
   DLIA_CHECK(t.is_cuda(), name, " must be a GPU tensor");
@@ -47,6 +53,7 @@ inline void check_rows(const Tensor& t, const char* name) {
 // out[r,:] = norm(x[row_idx[r] or r,:] (+addend -> x)) * w (+ b); mode 0 rms, 1 layernorm, 2 fold only.
 static void norm_impl(Tensor out, Tensor x, OptTensor delta, OptTensor partial, int64_t splits, OptTensor pbias,
                       const Tensor& w, OptTensor b, OptTensor row_idx, double eps, int64_t mode, OptTensor qscale) {
+  DLIA_ON_DEVICE_OF(out);
   check_bf16(x, "x"); check_bf16(w, "w");
   check_rows(out, "out"); check_rows(x, "x");
   float* qs = nullptr;
@@ -113,6 +120,7 @@ void norm_q(Tensor out_q, Tensor qscale, Tensor x, OptTensor delta, OptTensor pa
 }
 
 void embed(Tensor out, const Tensor& ids, OptTensor pos, const Tensor& wte, OptTensor wpe) {
+  DLIA_ON_DEVICE_OF(out);
   check_bf16(out, "out"); check_bf16(wte, "wte"); check_i32(ids, "ids");
   DLIA_CHECK(out.is_contiguous() && wte.is_contiguous() && wte.dim() == 2, "embed: contiguous 2-D tables");
   const int64_t T = ids.numel(), H = wte.size(1);
@@ -154,6 +162,7 @@ static void rope_kvwrite_impl(Tensor qkv, OptTensor partial, int64_t splits, Opt
                               OptTensor kv_scale, const Tensor& cos_t, const Tensor& sin_t,
                               const Tensor& tok_pos, const Tensor& tok_seq, const Tensor& block_table,
                               int64_t Hq, int64_t Hkv, int64_t D, bool use_rope) {
+  DLIA_ON_DEVICE_OF(qkv);
   check_bf16(qkv, "qkv");
   DLIA_CHECK(qkv.dim() == 2 && qkv.is_contiguous() && qkv.size(1) == (Hq + 2 * Hkv) * D, "qkv must be [T,(Hq+2Hkv)*D]");
   DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
@@ -223,6 +232,7 @@ int64_t large_gemm_kernel(int64_t which) {
 // wscale given: wp holds fp8 e4m3 weights (1 byte each) and wscale one fp32 scale per packed row.
 static void gemm_impl(Tensor out, const Tensor& x, const Tensor& wp, OptTensor wscale, OptTensor bias,
                       OptTensor residual, OptTensor workspace, int64_t N, int64_t epi, int64_t splitk, int64_t ntw) {
+  DLIA_ON_DEVICE_OF(out);
   check_bf16(x, "x"); check_rows(x, "x"); check_dev(out, "out"); check_dev(wp, "wp");
   const int64_t M = x.size(0), K = x.size(1);
   DLIA_CHECK(K % 128 == 0, "K must be a multiple of 128");
@@ -332,6 +342,7 @@ void gemm_w8(Tensor out, const Tensor& x, const Tensor& wp, const Tensor& wscale
 
 // q[M,K] (uint8, e4m3), scale[M] (fp32) <- x[M,K] (bf16): per-row dynamic quantisation
 void quant_rows(Tensor q, Tensor scale, const Tensor& x) {
+  DLIA_ON_DEVICE_OF(q);
   check_bf16(x, "x"); check_rows(x, "x"); check_dev(q, "q"); check_f32(scale, "scale");
   const int64_t M = x.size(0), K = x.size(1);
   DLIA_CHECK(K % 8 == 0, "K must be a multiple of 8");
@@ -346,6 +357,7 @@ void quant_rows(Tensor q, Tensor scale, const Tensor& x) {
 void gemm_a8w8(Tensor out, const Tensor& xq, const Tensor& xscale, const Tensor& wp, const Tensor& wscale,
                OptTensor bias, OptTensor residual, OptTensor workspace, int64_t N, int64_t epi, int64_t splitk,
                int64_t ntw) {
+  DLIA_ON_DEVICE_OF(out);
   check_dev(out, "out"); check_dev(xq, "xq"); check_dev(wp, "wp"); check_f32(xscale, "xscale"); check_f32(wscale, "wscale");
   DLIA_CHECK(xq.scalar_type() == at::kByte && xq.dim() == 2 && xq.stride(1) == 1, "xq must be uint8 [M, K]");
   const int64_t M = xq.size(0), K = xq.size(1);
@@ -433,6 +445,7 @@ static void paged_attention_impl(Tensor out, const Tensor& qkv, const Tensor& kv
                                  const Tensor& q_start, const Tensor& ctx_lens, const Tensor& block_table,
                                  OptTensor slots, OptTensor partial, int64_t max_q_len, int64_t Hq, int64_t Hkv,
                                  int64_t D, double scale, int64_t splits) {
+  DLIA_ON_DEVICE_OF(out);
   check_bf16(out, "out"); check_bf16(qkv, "qkv"); check_rows(out, "out"); check_rows(qkv, "qkv");
   DLIA_CHECK(D == 64 || D == 128, "head_dim must be 64 or 128");
   DLIA_CHECK(Hq % Hkv == 0, "Hq must be a multiple of Hkv");
@@ -488,6 +501,7 @@ static void sample_impl(Tensor out_tokens, const Tensor& logits, const Tensor& t
                         const Tensor& top_p, const Tensor& seeds, const Tensor& steps, int64_t vocab,
                         OptTensor dbg_probs, OptTensor dbg_ids, OptTensor chunk_max, OptTensor ids_out = c10::nullopt,
                         bool advance_steps = false, OptTensor ctx_advance = c10::nullopt) {
+  DLIA_ON_DEVICE_OF(out_tokens);
   check_i32(out_tokens, "out_tokens"); check_dev(logits, "logits");
   DLIA_CHECK(logits.scalar_type() == at::kFloat && logits.dim() == 2 && logits.stride(1) == 1, "logits must be fp32 [R, >=vocab]");
   const int64_t R = logits.size(0);
@@ -559,6 +573,7 @@ void sample_step(Tensor out_tokens, const Tensor& logits, OptTensor chunk_max, c
 // every 32-column chunk of every row over the columns < vocab (the sampler's guide). `workspace` as for gemm.
 void gemm_head(Tensor logits, Tensor chunk_max, const Tensor& x, const Tensor& wp, OptTensor workspace, int64_t N,
                int64_t vocab) {
+  DLIA_ON_DEVICE_OF(logits);
   check_bf16(x, "x"); check_rows(x, "x"); check_dev(logits, "logits"); check_dev(wp, "wp"); check_dev(chunk_max, "chunk_max");
   const int64_t M = x.size(0), K = x.size(1);
   DLIA_CHECK(M >= 1, "gemm_head: no rows");
@@ -591,6 +606,7 @@ void gemm_head(Tensor logits, Tensor chunk_max, const Tensor& x, const Tensor& w
 
 // dst[rows[r], :] = src[r, :] (int32 table rows; rows outside dst are skipped)
 void scatter_rows(Tensor dst, const Tensor& rows, const Tensor& src) {
+  DLIA_ON_DEVICE_OF(dst);
   check_i32(dst, "dst"); check_i32(rows, "rows"); check_i32(src, "src");
   DLIA_CHECK(dst.dim() == 2 && src.dim() == 2 && src.size(1) == dst.size(1) && rows.dim() == 1 && rows.numel() == src.size(0),
              "scatter_rows: dst [R, C], rows [n], src [n, C]");
@@ -600,12 +616,14 @@ void scatter_rows(Tensor dst, const Tensor& rows, const Tensor& src) {
 
 // dst.flat[idx[i]] = val[i] (int32; indices outside dst are skipped)
 void scatter(Tensor dst, const Tensor& idx, const Tensor& val) {
+  DLIA_ON_DEVICE_OF(dst);
   check_i32(dst, "dst"); check_i32(idx, "idx"); check_i32(val, "val");
   DLIA_CHECK(idx.dim() == 1 && val.dim() == 1 && idx.numel() == val.numel(), "scatter: idx [n], val [n]");
   dlia_scatter_i32(dst.data_ptr<int>(), idx.data_ptr<int>(), val.data_ptr<int>(), (int)idx.numel(), (long)dst.numel(), cur_stream());
 }
 
 void advance(Tensor x, int64_t delta) {
+  DLIA_ON_DEVICE_OF(x);
   check_i32(x, "x");
   dlia_advance_i32(x.data_ptr<int>(), (int)x.numel(), (int)delta, cur_stream());
 }

@@ -325,6 +325,13 @@ class Engine:
     # ---- scheduler thread ------------------------------------------------------------------
     def _loop(self):
         try:
+            # HIP's current device is per thread: this thread drives stage 0's streams, graphs and kernels
+            rt = getattr(self.head, "rt", None)
+            if rt is not None and getattr(rt, "on_gpu", False):
+                import torch
+                dev = torch.device(rt.device)
+                if dev.index is not None:
+                    torch.cuda.set_device(dev)
             while not self._stop:
                 progressed = False
                 while self._inbox:

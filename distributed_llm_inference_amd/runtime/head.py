@@ -416,6 +416,8 @@ def head_main(runtime, cin, res, idle_beat_s: float = 0.5) -> int:
         # step's tokens do not wait behind an earlier, longer prefill chunk of another micro-batch.
         waiting = []
         closing = False
+        if runtime.on_gpu and torch.device(runtime.device).index is not None:
+            torch.cuda.set_device(torch.device(runtime.device))      # (HIP's current device is per thread)
         while True:
             try:
                 item = pending.get(timeout=None if not waiting else 50e-6)
