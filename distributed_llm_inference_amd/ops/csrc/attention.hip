@@ -354,6 +354,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4))) void
   paged_attn_body<D, 1, KV8, 1, false>(p, blockIdx.x);
 }
 
+// The same one-wave-per-item body in a fixed number of 4-wave workgroups (one wave per SIMD) that walk the item list
+// with a stride: an experiment switch (DLIA_ATTN_PERSIST=<workgroups>, off by default). A CU that runs a workgroup of
+// the four-wave GEMM (368 of a SIMD lane's 512 registers) has room for exactly one of these, so with one workgroup per
+// CU attention waves of one micro-batch can sit beside GEMM waves of the other instead of taking turns with them.
+template <int D, bool KV8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void paged_attn_lean_persist_kernel(AttnParams p, long nitems) {
+  const long first = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (long item = first; item < nitems; item += (long)gridDim.x * 4) paged_attn_body<D, 1, KV8, 1, false>(p, item);
+}
+
 // Merge split-KV partials. One workgroup per (b, kv head, query tile); thread -> (column, 4 dims).
 template <int D, int NT>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
@@ -703,7 +713,11 @@ static void launch_attn(const AttnParams& p, hipStream_t stream) {
   const long nitems = (long)p.B * p.Hkv * p.qtiles * p.splits;
   constexpr size_t smem = 4 * NT * 64 * 2 * 4 + 4 * (D / 16) * NT * 64 * 16;
   const long thr = wave_per_item_threshold();
-  if (NT == 1 && thr > 0 && nitems >= thr) {
+  const char* pe = getenv("DLIA_ATTN_PERSIST");               // read per launch (a captured graph keeps what it was captured with)
+  const long persist = pe ? atol(pe) : 0L;
+  if (NT == 1 && thr > 0 && nitems >= thr && persist > 0 && nitems >= persist * 4 && !p.kv_scale) {
+    hipLaunchKernelGGL((paged_attn_lean_persist_kernel<D, false>), dim3((unsigned)persist), dim3(256), 0, stream, p, nitems);
+  } else if (NT == 1 && thr > 0 && nitems >= thr) {
     if (p.kv_scale) hipLaunchKernelGGL((paged_attn_lean_kernel<D, true>), dim3((unsigned)nitems), dim3(64), 0, stream, p);
     else            hipLaunchKernelGGL((paged_attn_lean_kernel<D, false>), dim3((unsigned)nitems), dim3(64), 0, stream, p);
   } else if (p.kv_scale) hipLaunchKernelGGL((paged_attn_kernel<D, NT, true>), dim3((unsigned)nitems), dim3(256), smem, stream, p);

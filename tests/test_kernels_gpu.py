@@ -700,6 +700,22 @@ def test_attention_decode_one_wave_per_item(K, geom, kv8):
     _attn_case(K, Hq, Hkv, D, ctx_lens=ctx, q_lens=[1] * B, splits=1, kv8=kv8)
 
 
+@pytest.mark.parametrize("workgroups", [64, 256])
+@pytest.mark.parametrize("geom", [(32, 8, 128), (32, 4, 64)])
+def test_attention_decode_persistent_workgroups(K, geom, workgroups, monkeypatch):
+    """The experiment switch DLIA_ATTN_PERSIST: the one-wave-per-item body in a fixed number of 4-wave
+    workgroups that walk the item list with a stride (item counts that are not multiples of the stride,
+    workgroups whose last turn has fewer than four items)."""
+    Hq, Hkv, D = geom
+    monkeypatch.setenv("DLIA_ATTN_PERSIST", str(workgroups))
+    B = 1024 // Hkv + 7
+    g = torch.Generator().manual_seed(Hq + D + workgroups)
+    ctx = torch.randint(0, 200, (B,), generator=g).tolist()
+    ctx[:6] = [0, 1, 31, 32, 33, 64]
+    ctx[-1] = 700
+    _attn_case(K, Hq, Hkv, D, ctx_lens=ctx, q_lens=[1] * B, splits=1)
+
+
 def test_attention_decode_one_wave_per_item_with_split_kv(K):
     ctx = [5, 700, 64, 333] * 10 + [1, 31]
     _attn_case(K, 32, 8, 128, ctx_lens=ctx, q_lens=[1] * len(ctx), splits=4)          # 42 x 8 x 4 = 1344 items
