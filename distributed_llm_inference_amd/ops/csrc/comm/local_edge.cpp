@@ -173,6 +173,14 @@ int dlia_ledge_query(void* h, int token, int recv_side) {
   return lfail("hipEventQuery", q);
 }
 
+// Messages whose send has been enqueued and whose receive has not been posted yet: a receive posted while this
+// is > 0 does not wait on the host.
+int dlia_ledge_pending(void* h) {
+  LocalEdge* e = static_cast<LocalEdge*>(h);
+  const uint64_t s = e->sent.load(std::memory_order_acquire), r = e->received.load(std::memory_order_acquire);
+  return s > r ? (int)(s - r) : 0;
+}
+
 void dlia_ledge_set_timeout(void* h, int ms) { static_cast<LocalEdge*>(h)->recv_timeout_ms = ms; }
 
 int dlia_ledge_abort(void* h) { static_cast<LocalEdge*>(h)->aborted.store(1); return 0; }

@@ -32,6 +32,7 @@ def _lib():
             "dlia_ledge_wait": (ci, [vp, ci, ci, vp]),
             "dlia_ledge_query": (ci, [vp, ci, ci]),
             "dlia_ledge_set_timeout": (None, [vp, ci]),
+            "dlia_ledge_pending": (ci, [vp]),
             "dlia_ledge_send_stream": (vp, [vp]),
             "dlia_ledge_abort": (ci, [vp]),
             "dlia_ledge_close": (ci, [vp]),
@@ -95,6 +96,10 @@ class LocalDeviceEdge(Edge):
         if tok < 0:
             raise LocalEdgeError(f"recv on {self.name}: {self.L.dlia_ledge_last_error().decode(errors='replace')}")
         return _LocalHandle(self, tok, 1, keep=buf)
+
+    def pending(self) -> int:
+        """Messages already sent (enqueued) and not yet received: `recv` does not block while this is > 0."""
+        return int(self.L.dlia_ledge_pending(self.h))
 
     def native_ends(self):
         """(handle, send, recv, wait for a send, wait for a receive, last error text) for the native stage loop."""

@@ -62,10 +62,54 @@ class _EventHandle(Handle):
         return self.event.query()
 
 
+class _Deferred:
+    """A submitted step of an in-process GPU pipeline whose token receive has not been posted yet."""
+
+    __slots__ = ("mb", "n", "buf", "slot", "got", "ev")
+
+    def __init__(self, mb, n, buf, slot):
+        self.mb, self.n, self.buf, self.slot = mb, n, buf, slot
+        self.got = self.ev = None            # set when the receive is posted
+
+
+class _DeferredHandle(Handle):
+    """Arrival of a deferred step's fed-back tokens: the next step of the micro-batch waits for it on its
+    stream, which needs the receive posted first (the only place where the host may wait)."""
+
+    def __init__(self, head, entry):
+        self.head, self.entry = head, entry
+
+    def wait(self):
+        self.head._pump(upto=self.entry)
+        torch.cuda.current_stream().wait_event(self.entry.got)
+
+    def done(self) -> bool:
+        self.head._pump()
+        return self.entry.got is not None and self.entry.got.query()
+
+
+class _DeferredResult(StepResult):
+    def __init__(self, head, entry):
+        super().__init__(host=entry.slot[1])
+        self.head, self.entry = head, entry
+
+    def ready(self) -> bool:
+        self.head._pump()
+        return self.entry.ev is not None and self.entry.ev.query()
+
+    def get(self) -> List[int]:
+        self.head._pump(upto=self.entry)
+        self.entry.ev.synchronize()
+        return self.host.tolist()
+
+
 class LocalHead:
     """Stage 0 in this process. Over RCCL hops nothing here blocks the host. Over the in-process device
-    hops of a single-process GPU pipeline (tests, rehearsals) posting the feedback receive waits on the
-    host until the last stage's thread has enqueued the matching send — at most `hop_timeout_s` x stages."""
+    hops of a single-process GPU pipeline (tests, rehearsals) a receive can only be posted once the last
+    stage's thread has enqueued the matching send: the token receive of a step is therefore posted when the
+    scheduler polls the result and finds the message there, not at submission, so submitting never waits.
+    The host waits (at most `hop_timeout_s` x stages) only where it has to: a result read before it is ready,
+    or the next step of a micro-batch submitted before its fed-back tokens were sent."""
 
     remote = False
 
@@ -85,6 +129,9 @@ class LocalHead:
         # host copy run on a side stream, which has to wait for the last stage anyway.
         self._ring: Dict[tuple, list] = {}           # (micro-batch, n) -> [(staging, pinned host, event), ...]
         self._ring_pos: Dict[tuple, int] = {}
+        # in-process device hops: steps whose token receive is still to be posted, in submission order
+        self._deferred: List[_Deferred] = []
+        self._defer = self.on_gpu and self.num_stages > 1 and hasattr(self.links.fb_data, "pending")
 
     # ---- how a descriptor will run ----------------------------------------------------------
     def graph_decode(self, desc: StepBatch) -> bool:
@@ -98,6 +145,11 @@ class LocalHead:
         that wait would block the calling thread, so a replay step is only submitted once they
         have arrived."""
         h = self._last_fb.get(mb)
+        if isinstance(h, _DeferredHandle):
+            # in-process device hops: the step would wait on the HOST for the last stage's thread to enqueue
+            # the tokens' send, so it is submitted once that has happened (and their receive been posted)
+            self._pump()
+            return h.entry.got is not None
         if self.on_gpu or self.num_stages == 1 or h is None:
             return True
         return h.done()
@@ -144,6 +196,14 @@ class LocalHead:
                 slot[2] = ev
                 return StepResult(event=ev, host=host)
             buf = rt.fb_buffer(mb, n_res)
+            if self._defer:
+                slot = self._slot(mb, n_res)
+                slot[2] = None
+                entry = _Deferred(mb, n_res, buf, slot)
+                self._deferred.append(entry)
+                self._pump()
+                self._last_fb[mb] = _DeferredHandle(self, entry)
+                return _DeferredResult(self, entry)
             if self.on_gpu:
                 slot = self._slot(mb, n_res)
                 host = slot[1]
@@ -162,6 +222,28 @@ class LocalHead:
             h = self.links.fb_data.recv(buf) if n_res else None
             self._last_fb[mb] = h
             return StepResult(tokens=buf, handle=h)
+
+    def _pump(self, upto: Optional[_Deferred] = None):
+        """Posts the token receives of deferred steps, oldest first, for as long as their messages are there
+        (a receive then returns at once). With `upto`: also the ones that are not, up to and including that
+        step — the host then waits in `recv` for the last stage's thread, with the hop's deadline."""
+        fb = self.links.fb_data
+        while self._deferred:
+            e = self._deferred[0]
+            forced = upto is not None and upto.ev is None
+            if e.n and not forced and fb.pending() == 0:
+                return
+            ev, got = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(self._res_stream):
+                if e.n:
+                    fb.recv(e.buf).wait()
+                got.record()
+                if e.n:
+                    e.slot[1].copy_(e.buf, non_blocking=True)
+                ev.record()
+            e.slot[2] = ev
+            e.got, e.ev = got, ev
+            self._deferred.pop(0)
 
     def shutdown(self):
         try:

@@ -2,6 +2,7 @@
 Stages of a multi-stage pipeline share the one GPU here (loopback links, one thread per stage);
 what is exercised is everything except the RCCL wire: static graph buffers as receive targets,
 token feedback into the stage-0 graph input, replay descriptors, continuous batching."""
+import time
 import pytest
 import torch
 
@@ -517,6 +518,37 @@ def test_stages_behind_stage_0_serve_replay_steps_natively(monkeypatch):
     monkeypatch.setenv("DLIA_NATIVE_LOOP", "0")                       # the Python stage loop over the same hops
     got, snap, stats = run_pp(3)
     assert got == want and snap["fatal"] is None and stats == [None, None]
+
+
+def test_in_process_pipeline_submits_without_waiting_for_the_last_stage():
+    """Stage threads of one process hand tokens back over an in-process device hop, whose receive can only
+    be posted once the sender has enqueued its message. The scheduler thread must not wait for that: with
+    the last stage asleep for a second at its third step, no call of the head's `submit` takes anywhere
+    near that long (the token receive is posted when the result is polled and found), the scheduler keeps
+    polling meanwhile, and the request completes with the tokens of an undisturbed run."""
+    ps = prompts(3, seed=5)
+    want, _ = run(cfg(max_seq_len=128), ps, greedy(12))
+    pipe = LocalPipeline(cfg(pp_size=2, num_micro_batches=2, max_seq_len=128, fault_inject="stage1:stall@3:1.0"))
+    try:
+        head = pipe.engine.head
+        slow, inner = [], head.submit
+
+        def timed(d):
+            t0 = time.perf_counter()
+            try:
+                return inner(d)
+            finally:
+                slow.append(time.perf_counter() - t0)
+
+        head.submit = timed
+        reqs = [pipe.engine.submit(p, greedy(12)) for p in ps]
+        outs = [r.wait(120).output for r in reqs]
+        pipe.engine.wait_idle()
+        snap = pipe.engine.snapshot()
+    finally:
+        pipe.close()
+    assert outs == want and snap["fatal"] is None and snap["failed"] == 0
+    assert slow and max(slow) < 0.5, max(slow)
 
 
 @pytest.mark.parametrize("native_loop", [False, True], ids=["python stage loop", "native stage loop"])
