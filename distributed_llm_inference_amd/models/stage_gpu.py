@@ -17,6 +17,7 @@ Same interface as `RefStage`; what it replaces in the reference is `Worker.proce
 """
 from __future__ import annotations
 
+import gc
 import math
 import os
 import threading
@@ -112,7 +113,7 @@ class _MicroBatchState:
 # `LocalPipeline`) a second stage thread doing that while the first is mid-capture invalidated the first's
 # capture now and then (`hipErrorStreamCaptureInvalidated` at capture end, the stage's engine then fails every
 # request). A stage process of a real pipeline holds one stage: the lock is never contended there.
-_CAPTURE_LOCK = threading.Lock()
+_CAPTURE_LOCK = threading.RLock()
 
 
 class GpuStage:
@@ -644,6 +645,12 @@ class GpuStage:
         st = self._mbs.get((mb, B))
         if st is not None:
             return st
+        # (several stages as threads of one process: a gigabyte of workspace is not allocated, nor an old
+        # state with its graph dropped, while another stage's thread is capturing)
+        with _CAPTURE_LOCK:
+            return self._new_mb_state(mb, B)
+
+    def _new_mb_state(self, mb: int, B: int) -> _MicroBatchState:
         if B not in self.graph_sizes:                      # an odd size (a test, a probe): it replaces the previous odd one
             for k in [k for k in self._mbs if k[0] == mb and k[1] not in self.graph_sizes]:
                 del self._mbs[k]
@@ -774,8 +781,18 @@ class GpuStage:
             # Thread-local capture mode: only this thread issues the captured work, but a stage process
             # of a multi-GPU pipeline also runs RCCL's watchdog thread (event queries at any time), and
             # under the default global mode a HIP call from another thread invalidates the capture.
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._decode_body(st)
+            # No cyclic garbage collection inside the capture: the collector runs in whichever thread trips its
+            # counter, and what it finds may be another thread's (a closed pipeline's graphs, pools, pinned buffers),
+            # whose release is not a thing to do on a capturing thread (seen once: the process aborted inside a
+            # collection that started in a capturing stage thread of a 5-stage in-process pipeline).
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._decode_body(st)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             st.ctx.copy_(saved[0]); st.steps.copy_(saved[1]); st.ids.copy_(saved[2])
             st.graph = g
             self.graph_captures += 1

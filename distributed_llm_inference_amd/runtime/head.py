@@ -17,6 +17,7 @@ import queue
 import struct
 import threading
 import time
+import weakref
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -77,28 +78,39 @@ class _DeferredHandle(Handle):
     stream, which needs the receive posted first (the only place where the host may wait)."""
 
     def __init__(self, head, entry):
-        self.head, self.entry = head, entry
+        # (a weak reference: the head keeps its latest handles, and a cycle through it would leave the whole
+        # pipeline — executors, graphs, KV cache — to the cyclic collector, to be released at some later time on
+        # whichever thread trips it, instead of when the pipeline is closed)
+        self.head, self.entry = weakref.ref(head), entry
 
     def wait(self):
-        self.head._pump(upto=self.entry)
+        head = self.head()
+        if head is not None:
+            head._pump(upto=self.entry)
         torch.cuda.current_stream().wait_event(self.entry.got)
 
     def done(self) -> bool:
-        self.head._pump()
+        head = self.head()
+        if head is not None:
+            head._pump()
         return self.entry.got is not None and self.entry.got.query()
 
 
 class _DeferredResult(StepResult):
     def __init__(self, head, entry):
         super().__init__(host=entry.slot[1])
-        self.head, self.entry = head, entry
+        self.head, self.entry = weakref.ref(head), entry
 
     def ready(self) -> bool:
-        self.head._pump()
+        head = self.head()
+        if head is not None:
+            head._pump()
         return self.entry.ev is not None and self.entry.ev.query()
 
     def get(self) -> List[int]:
-        self.head._pump(upto=self.entry)
+        head = self.head()
+        if head is not None:
+            head._pump(upto=self.entry)
         self.entry.ev.synchronize()
         return self.host.tolist()
 
@@ -246,6 +258,8 @@ class LocalHead:
             self._deferred.pop(0)
 
     def shutdown(self):
+        self._deferred.clear()
+        self._last_fb.clear()
         try:
             if self.links.next_ctrl is not None:
                 self.links.next_ctrl.put(control(KIND_SHUTDOWN).to_bytes())
