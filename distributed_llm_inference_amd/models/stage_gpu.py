@@ -797,6 +797,17 @@ class GpuStage:
             st.graph = g
             self.graph_captures += 1
 
+    def drop_graphs(self):
+        """Drops the captured graphs (with their memory pools) and the static decode buffers now, on the calling
+        thread. A pipeline that is closed does this instead of leaving it to whenever the last reference goes:
+        were that the cyclic collector, it would run on whichever thread trips it — possibly a stage thread of
+        the next pipeline, in the middle of its steps or of a capture."""
+        with _CAPTURE_LOCK:
+            torch.cuda.synchronize(self.device)          # no replay of theirs is still running
+            for st in self._mbs.values():
+                st.graph = None
+            self._mbs.clear()
+
     # ---- introspection ----------------------------------------------------------------------
     def memory_report(self) -> Dict[str, float]:
         gib = 1 << 30

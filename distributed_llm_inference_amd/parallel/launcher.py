@@ -152,6 +152,7 @@ class LocalPipeline:
         for ex in exs:
             settle_kv(ex, self.kv_blocks, cfg.warm_decode_graphs)
         self.executors = exs
+        self._own_executors = executors is None
         self.tracer = make_tracer(cfg.trace_path)      # one process: all stages share the tracer
         self.runtimes = [StageRuntime(ex, l, board=self.board, fault=cfg.fault_inject, tracer=self.tracer, decode_streams=cfg.decode_streams, debug_top5=cfg.debug_top5,
                                       trace_path=cfg.trace_path if l.stage == 0 else None)
@@ -192,6 +193,10 @@ class LocalPipeline:
         if not any(t.is_alive() for t in self.threads):
             for rt in self.runtimes:                  # device hops and rings of an in-process GPU pipeline
                 rt.links.close()
+            if self._own_executors and self.engine.fatal is None:
+                for ex in self.executors:             # graphs and static buffers go now, on this thread
+                    if hasattr(ex, "drop_graphs"):
+                        ex.drop_graphs()
         self.board.close()
 
 
