@@ -156,3 +156,38 @@ def test_micro_batch_shrinks_when_the_kv_cache_would_not_fit(monkeypatch):
     # 70 GB of e4m3 weights do leave room for that
     assert fit(32, 1, "llama-3-70b") == 1024 and fit(100, 1, "llama-3-70b") == 512
     assert fit(100, 1, "llama-3-70b", "fp8") == 1024
+
+
+def test_overlap_analysis_reads_a_two_stream_kernel_trace(tmp_path, capsys):
+    """bench/overlap_analysis.py on a synthetic rocprofv3 kernel trace: kernel classes from names and grids,
+    O told from down by what precedes it on its stream, and the overlap shares of two streams."""
+    spec = importlib.util.spec_from_file_location("overlap_analysis", os.path.join(ROOT, "bench", "overlap_analysis.py"))
+    oa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(oa)
+    assert oa.klass("void dlia::gemm_pingpong_kernel<false, false>(dlia::GemmParams)", 458752, 512) == "gate_up"
+    assert oa.klass("void dlia::gemm_pingpong_kernel<false, true>(dlia::GemmParams)", 2064384, 512) == "lm_head"
+    assert oa.klass("void dlia::paged_attn_lean_kernel<128, false>(dlia::AttnParams)", 1048576, 64) == "attn"
+    head = ("Kind,Agent_Id,Queue_Id,Stream_Id,Thread_Id,Dispatch_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,"
+            "End_Timestamp,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Workgroup_Size_X,"
+            "Workgroup_Size_Y,Workgroup_Size_Z,Grid_Size_X,Grid_Size_Y,Grid_Size_Z")
+    gemm, attn = "void dlia::gemm_pingpong_kernel<false, false>(dlia::GemmParams)", "void dlia::paged_attn_lean_kernel<128, false>(dlia::AttnParams)"
+
+    def row(i, stream, name, t0, t1, grid, wg):
+        return f'"KERNEL_DISPATCH","Agent 1",{stream},{stream},1,{i},1,"{name}",{i},{t0},{t1},0,0,64,0,32,{wg},1,1,{grid},1,1'
+
+    lines = [head,
+             row(1, 1, attn, 1_000_000, 1_300_000, 1048576, 64),        # stream 1: attention, then O (128 workgroups)
+             row(2, 1, gemm, 1_300_000, 1_400_000, 65536, 512),
+             row(3, 2, gemm, 1_000_000, 1_400_000, 458752, 512),        # stream 2: gate/up beside both, then down
+             row(4, 2, gemm, 1_400_000, 1_600_000, 65536, 512)]
+    d = tmp_path / "trace"
+    d.mkdir()
+    (d / "1_kernel_trace.csv").write_text("\n".join(lines) + "\n")
+    sys.argv = ["overlap_analysis.py", str(d), "10"]
+    oa.main()
+    out = capsys.readouterr().out
+    stats = {l.split()[0]: l for l in out.splitlines() if l and l.split()[0] in ("gate_up", "attn", "o", "down")}
+    assert set(stats) == {"gate_up", "attn", "o", "down"}
+    assert "attn:75%" in stats["gate_up"] and "o:25%" in stats["gate_up"]
+    assert "gate_up:100%" in stats["attn"] and "gate_up:100%" in stats["o"]
+    assert float(stats["down"].split()[3]) == 100.0                       # down ran alone
