@@ -290,7 +290,7 @@ def _deadline(seconds: float):
     return t
 
 
-def _fit_batch(a, nmb: int, max_seq: int, world: int) -> int:
+def _fit_batch(a, nmb: int, max_seq: int, world: int, quiet: bool = False) -> int:
     """The KV cache holds every in-flight sequence for prompt + warm-up + timed steps. A long run
     (--steps in the hundreds) at 2 x 1024 sequences per GPU, or a 70B model on one GPU, would ask
     for more than the device has: halve the micro-batch until the largest stage's share fits in 85 %
@@ -311,10 +311,24 @@ def _fit_batch(a, nmb: int, max_seq: int, world: int) -> int:
     batch = a.batch
     while batch > 64 and nmb * batch * max_seq * spec.kv_bytes_per_token_per_layer(1 if a.kv_dtype == "fp8" else 2) * layers > budget:
         batch //= 2
-    if batch != a.batch and int(os.environ.get("RANK", "0")) == 0:
+    if batch != a.batch and not quiet and int(os.environ.get("RANK", "0")) == 0:
         sys.stderr.write(f"bench.py: KV cache for {nmb} x {a.batch} sequences of {max_seq} tokens does not fit; "
                          f"using micro-batches of {batch}\n")
     return batch
+
+
+def _fit_schedule(a, nmb: int, max_seq: int, world: int, spares: int):
+    """(micro-batch size, micro-batches) that fit. When a long run's KV cache does not hold every micro-batch
+    at full size the spare micro-batches go first (two of them are worth ~3 % of a full pipeline,
+    bench/pipeline_sim.py); the micro-batch is halved (2048 -> 1024 rows: ~5 %) only if that is not enough."""
+    want = a.batch
+    if spares and _fit_batch(a, nmb, max_seq, world, quiet=True) < want and \
+            _fit_batch(a, nmb - spares, max_seq, world, quiet=True) == want:
+        nmb -= spares
+        if int(os.environ.get("RANK", "0")) == 0:
+            sys.stderr.write(f"bench.py: KV cache for {nmb + spares} x {want} sequences of {max_seq} tokens does not fit; "
+                             f"running {nmb} micro-batches (no spares)\n")
+    return _fit_batch(a, nmb, max_seq, world), nmb
 
 
 def _combined_hops(ranks):
@@ -423,7 +437,8 @@ def main():
     extra = 2 * (a.latency_steps + lat_warm) if lat_rows else 0
     max_seq = ((a.prompt_len + a.steps + a.warmup + extra + 2 + 31) // 32) * 32
     if not a.cpu:
-        a.batch = _fit_batch(a, nmb, max_seq, max(1, world))
+        spares = 2 if (world > 1 and wide and not a.micro_batches) else 0
+        a.batch, nmb = _fit_schedule(a, nmb, max_seq, max(1, world), spares)
         lat_rows = min(lat_rows, a.batch)
     # the low-latency regions run decode steps of `lat_rows` rows and of one row on micro-batch 0:
     # captured at first use (only micro-batch 0 ever runs them), like the sizes a server keeps for light load

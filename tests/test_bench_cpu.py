@@ -157,6 +157,17 @@ def test_micro_batch_shrinks_when_the_kv_cache_would_not_fit(monkeypatch):
     assert fit(32, 1, "llama-3-70b") == 1024 and fit(100, 1, "llama-3-70b") == 512
     assert fit(100, 1, "llama-3-70b", "fp8") == 1024
 
+    # several stages: the two spare micro-batches go before the micro-batch is halved
+    def schedule(steps, world=8, batch=2048):
+        a = types.SimpleNamespace(model="llama-3-8b", partition="balanced", batch=batch, prompt_len=128, steps=steps, warmup=10,
+                                  kv_dtype="bf16", dtype="bf16")
+        max_seq = ((a.prompt_len + a.steps + a.warmup + 54 + 2 + 31) // 32) * 32
+        return b._fit_schedule(a, 2 * world + 2, max_seq, world, 2)
+
+    assert schedule(50) == (2048, 18)                       # the usual run: everything fits
+    assert schedule(150) == (2048, 16)                      # 18 x 2048 x 352 tokens x 20 KiB = 247 GiB do not fit, 16 x ... do
+    assert schedule(400)[0] < 2048                          # nothing but a smaller micro-batch helps
+
 
 def test_overlap_analysis_reads_a_two_stream_kernel_trace(tmp_path, capsys):
     """bench/overlap_analysis.py on a synthetic rocprofv3 kernel trace: kernel classes from names and grids,
