@@ -35,6 +35,8 @@
 #include <thread>
 #include <vector>
 
+#include "rccl_edge.h"
+
 namespace {
 
 constexpr uint32_t kDescMagic = 0x444C4942;     // "DLIB" (runtime/batch.py)
@@ -72,6 +74,11 @@ struct Mb {
   int send_tok = -1;                             // completion of the latest send out of out_ptr
   int fb_tok = -1;                               // stage 0 of several: arrival of the ids the next step reads (in_ptr)
   int last_slot = -1;                            //   and the host slot they were last copied to (its event guards in_ptr)
+  // a stage behind stage 0: end of the graph launch that last read in_ptr, recorded by THIS loop. While it is valid
+  // the next receive into in_ptr waits for that event only — not for everything queued on the micro-batch's stream,
+  // which several micro-batches share: the hidden states of micro-batch k + 2 then arrive while micro-batch k still
+  // computes on that stream, and the sender's hop stream is not held up behind this stage's compute.
+  hipEvent_t in_free = nullptr; bool in_free_ok = false;
   int32_t* host[kSlots] = {};
   hipEvent_t ev[kSlots] = {};
   int next = 0;
@@ -426,6 +433,7 @@ int dlia_stage_set_mb(void* h, int mb, void* exec, void* stream, void* in_ptr, s
   Mb& m = l->mbs[mb];
   m.exec = (hipGraphExec_t)exec; m.stream = (hipStream_t)stream; m.rows = rows;
   m.in_ptr = in_ptr; m.in_bytes = in_bytes; m.out_ptr = out_ptr; m.out_bytes = out_bytes;
+  m.in_free_ok = false;
   return 0;
 }
 
@@ -452,6 +460,9 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
   Loop* l = static_cast<Loop*>(h);
   if (hipSetDevice(l->device) != hipSuccess) return -1;
   if (!l->ein.h || !l->eout.h) { snprintf(l->err, sizeof(l->err), "stage loop without hops"); return -1; }
+  // whatever the Python loop ran since the last call may have read the input buffers too: the first receive of
+  // every micro-batch waits for its whole stream again
+  for (Mb& m : l->mbs) m.in_free_ok = false;
   const auto t_enter = std::chrono::steady_clock::now();
   int idle_spins = 0, since_check = 0;
   for (;;) {
@@ -496,8 +507,10 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
       *src = blk;
       HIPCHK(l, hipMemcpyAsync(l->table + (size_t)slot * l->max_blocks + pos, src, 4, hipMemcpyHostToDevice, m.stream));
     }
-    // the receive overwrites the input buffer: after its previous reader (the stream's earlier work)
-    const int rtok = l->ein.recv(l->ein.h, m.in_ptr, m.in_bytes, m.stream, nullptr);
+    // the receive overwrites the input buffer: after its previous reader — this loop's last launch of the
+    // micro-batch's graph when that is known, the stream's earlier work otherwise
+    const int rtok = m.in_free_ok ? l->ein.recv(l->ein.h, m.in_ptr, m.in_bytes, DLIA_NO_STREAM, m.in_free)
+                                  : l->ein.recv(l->ein.h, m.in_ptr, m.in_bytes, m.stream, nullptr);
     tl_stamp(l, rec, 0, m.stream);                            // the stream is free for this step from here on
     if (rtok < 0 || l->ein.wait(l->ein.h, rtok, m.stream) != 0) return hop_fail(l, "receive", l->ein);
     if (m.send_tok >= 0) {                                    // the graph overwrites the output buffer: after its last send
@@ -507,6 +520,9 @@ int dlia_stage_serve(void* h, void* prev_ring, void* next_ring, void* msg_out, u
     tl_stamp(l, rec, 1, m.stream);                            // input there, output buffer free: compute starts
     HIPCHK(l, hipGraphLaunch(m.exec, m.stream));
     tl_stamp(l, rec, 2, m.stream);
+    if (!m.in_free) HIPCHK(l, hipEventCreateWithFlags(&m.in_free, hipEventDisableTiming));
+    HIPCHK(l, hipEventRecord(m.in_free, m.stream));
+    m.in_free_ok = true;
     if (next_ring != nullptr && l->rput(next_ring, msg_out, (uint32_t)n, 5000) != 0) {   // descriptor first: the next stage posts its receive
       snprintf(l->err, sizeof(l->err), "next stage's descriptor ring: put failed");
       return -1;
@@ -646,6 +662,7 @@ void dlia_replay_destroy(void* h) {
       if (m.host[i]) (void)hipHostFree(m.host[i]);
       if (m.ev[i]) (void)hipEventDestroy(m.ev[i]);
     }
+  for (Mb& m : l->mbs) if (m.in_free) (void)hipEventDestroy(m.in_free);
   if (l->grow_stage) (void)hipHostFree(l->grow_stage);
   for (StepRec& r : l->tl.open)
     for (hipEvent_t e : r.e) if (e) (void)hipEventDestroy(e);
