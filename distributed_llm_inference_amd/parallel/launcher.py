@@ -17,6 +17,7 @@ exposing Flask through ngrok, with worker URLs pasted into the orchestrator sour
 from __future__ import annotations
 
 import dataclasses
+import gc
 import os
 import socket
 import threading
@@ -135,6 +136,10 @@ class LocalPipeline:
     def __init__(self, cfg: EngineConfig, executors: Optional[list] = None):
         from ..runtime.engine import Engine
         self.cfg = cfg
+        # What an earlier pipeline of this process left to the cyclic collector (executors, graphs, device
+        # buffers caught in a reference cycle) is released now, on this thread, not at some point during this
+        # pipeline's run on whichever of its threads trips the collector.
+        gc.collect()
         self.spec = resolve_spec(cfg)
         self.plans = plans_for(cfg, self.spec)
         self.job = f"dlia_{os.getpid()}_{uuid.uuid4().hex[:8]}"
