@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--side-stream", action="store_true", help="run the steps on a non-default stream")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8w"])
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 KV cache with per-(token, head) scales")
+    ap.add_argument("--zero-operands", action="store_true",
+                    help="diagnostic: the decoder layers' weights set to zero after packing (same instructions, same bytes moved, "
+                         "next to no switching in the matrix cores) - how much of a step's time is the power limit")
     a = ap.parse_args()
     spec = ModelSpec.from_pretrained(a.model)
     if a.layers:
@@ -45,6 +48,13 @@ def main():
     st = GpuStage(spec, plan, w, max_slots=B, max_seq_len=nblk * 32, num_blocks=B * nblk, max_tokens=max(B, 64),
                   max_batch=B, use_graphs=not a.no_graph, weight_dtype=a.dtype, kv_dtype=a.kv_dtype)
     del w
+    if a.zero_operands:
+        for layer in st.layers:
+            for t_ in layer.values():
+                if torch.is_tensor(t_):
+                    t_.zero_()
+        # (embedding and lm_head stay: the hidden state is then the embedding all the way, the logits differ from
+        # row to row and the sampler takes its usual path; with all-equal logits it walks whole rows)
     torch.cuda.synchronize()
     print(f"built in {time.time() - t0:.1f}s", st.memory_report(), flush=True)
     tables = {s: list(range(s * nblk, (s + 1) * nblk)) for s in range(B)}
